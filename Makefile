@@ -1,0 +1,42 @@
+# Builds, in-tree:
+#   simple-path-tracer_amd/lib/libspt_host.so  host side (scene JSON/OBJ/EXR -> spt_scene_desc, PNG)
+#   simple-path-tracer_amd/lib/libspt_hip.so   HIP kernels + C ABI (gfx950)
+#   simple-path-tracer_amd/lib/spt             CLI with the reference's flags (src/main.rs:26-41)
+#   oracle/liboracle.so                        CPU oracle (test infrastructure only)
+# FP contraction is disabled everywhere so the deterministic math of
+# include/spt_detmath.h gives identical bits on x86-64 and gfx950.
+PKG      := simple-path-tracer_amd
+LIBDIR   := $(PKG)/lib
+CXX      ?= g++
+HIPCC    ?= hipcc
+CXXFLAGS := -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fno-fast-math -Iinclude
+HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fgpu-rdc=0 \
+            -Wall -Wno-unused-function -Iinclude
+
+HOST_SRC := $(wildcard $(PKG)/csrc/host/*.cpp)
+HOST_HDR := $(wildcard $(PKG)/csrc/host/*.hpp) $(wildcard include/*.h)
+HIP_SRC  := $(wildcard $(PKG)/csrc/hip/*.hip)
+HIP_HDR  := $(wildcard $(PKG)/csrc/hip/*.h) $(wildcard include/*.h)
+
+.PHONY: all host hip cli oracle clean
+all: host oracle hip cli
+
+host: $(LIBDIR)/libspt_host.so
+hip: $(LIBDIR)/libspt_hip.so
+cli: $(LIBDIR)/spt
+oracle:
+	$(MAKE) -C oracle
+
+$(LIBDIR)/libspt_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
+
+$(LIBDIR)/libspt_hip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(LIBDIR)/spt: $(PKG)/csrc/cli/main.cpp $(LIBDIR)/libspt_host.so $(LIBDIR)/libspt_hip.so
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lspt_host -lspt_hip -Wl,-rpath,'$$ORIGIN'
+
+clean:
+	rm -rf $(LIBDIR) oracle/*.so oracle/_ref

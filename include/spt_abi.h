@@ -1,0 +1,287 @@
+/*
+ * spt_abi.h — C ABI of the MI355X path-tracing integrator (libspt_hip.so).
+ *
+ * This is the drop-in seam for the reference's renderer boundary
+ *     pub trait RendererT { fn render(&self, scene: &Scene, config: &OutputConfig); }
+ *                                            (reference src/renderer/mod.rs:16-19)
+ * selected by the renderer JSON "type" string in create_renderer
+ * (src/renderer/mod.rs:26-38) and called once from src/main.rs:61.  The reference
+ * has no FFI of its own; a Rust host adds a `Renderer::PathTracerHip` variant that
+ * flattens its `Scene` into the POD arrays below and calls these entry points
+ * (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; all pointers in descriptors are HOST pointers
+ *    borrowed for the duration of the call (the library copies what it keeps).
+ *  - every function returns spt_status (0 = OK); nothing panics/aborts/throws
+ *    across the boundary (the reference panics: src/renderer/pt.rs:287,
+ *    src/core/scene.rs:29-41); spt_last_error() gives a thread-local message.
+ *  - there is NO CPU fallback behind this ABI: without a usable gfx950 device
+ *    spt_scene_create fails with SPT_ERR_NO_DEVICE.
+ *  - all arithmetic is IEEE f32 (reference: glam Vec3A / Color f32).
+ */
+#ifndef SPT_ABI_H
+#define SPT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPT_ABI_VERSION 1
+
+typedef int32_t spt_status;
+enum {
+    SPT_OK = 0,
+    SPT_ERR_INVALID_ARG = 1,   /* null pointer, bad size, inconsistent descriptor */
+    SPT_ERR_NO_DEVICE = 2,     /* no HIP device / not gfx950 / device index out of range */
+    SPT_ERR_HIP = 3,           /* a HIP runtime call failed (message has the HIP error string) */
+    SPT_ERR_UNSUPPORTED = 4,   /* feature outside the hot-path scope (e.g. filter radius > 0.5) */
+    SPT_ERR_OUT_OF_MEMORY = 5
+};
+
+/* ---- geometry ----------------------------------------------------------------*/
+
+/* One node of a binary BVH, 32 B = two 16-B loads.
+ * Replaces the heap BvhNode {lc, rc, bbox, start, end} of src/primitive/bvh.rs:14-20.
+ *   inner: a = index of left child, b = index of right child (absolute, same array)
+ *   leaf : a = first item,  b = SPT_LEAF_FLAG | item count
+ * Items are triangles (BLAS, absolute index into tri_pos) or instances (TLAS). */
+#define SPT_LEAF_FLAG 0x80000000u
+typedef struct spt_bvh_node {
+    float bmin[3];
+    uint32_t a;
+    float bmax[3];
+    uint32_t b;
+} spt_bvh_node;
+
+/* Triangle positions in BLAS leaf order (MeshVertex.position of the three
+ * corners, src/primitive/triangle.rs:124-127). 48 B = three 16-B loads; the
+ * 4th lane of each row is padding (36 algorithmic bytes). */
+typedef struct spt_tri_pos {
+    float p0[3]; float pad0;
+    float p1[3]; float pad1;
+    float p2[3]; float pad2;
+} spt_tri_pos;
+
+/* Per-corner shading attributes of the same triangle, read once per hit
+ * (src/primitive/triangle.rs:188-212): 132 algorithmic bytes, padded to 144. */
+typedef struct spt_tri_attr {
+    float n[3][3];   /* normals        */
+    float t[3][3];   /* tangents       */
+    float b[3][3];   /* bitangents     */
+    float uv[3][2];  /* texcoords      */
+    float pad[3];
+} spt_tri_attr;
+
+typedef struct spt_sphere {   /* src/primitive/sphere.rs:8-12 */
+    float center[3];
+    float radius;
+} spt_sphere;
+
+typedef struct spt_mesh {     /* one TriMesh = one BLAS (src/primitive/triangle.rs:19-21) */
+    uint32_t root;            /* index of the BLAS root in blas_nodes */
+    uint32_t node_count;
+    uint32_t tri_first;       /* first triangle (tri_pos / tri_attr index) */
+    uint32_t tri_count;
+} spt_mesh;
+
+enum { SPT_PRIM_SPHERE = 0, SPT_PRIM_MESH = 1 };
+
+/* Instance = primitive + transform + surface (src/primitive/instance.rs:10-16).
+ * Matrices are stored as glam stores them: three columns then the translation;
+ * a point maps to ((c0*x + c1*y) + c2*z) + t, a vector without t
+ * (Affine3A::transform_point3a / transform_vector3a). */
+typedef struct spt_instance {
+    float inv[12];        /* trans_inv : world -> object                        */
+    float fwd[12];        /* trans     : object -> world                        */
+    float nrm[9];         /* trans_it = transpose(inverse(M).matrix3), 3 columns */
+    uint32_t prim_type;   /* SPT_PRIM_*                                          */
+    uint32_t prim_id;     /* sphere index or mesh index                          */
+    uint32_t surface;     /* index into surfaces                                 */
+    int32_t light;        /* index of this instance's ShapeLight in lights, -1 if not emissive
+                             (instance_light_map, src/core/scene_resources.rs:112-120) */
+    float bmin[3];        /* world bbox (Instance::bbox)                          */
+    float bmax[3];
+    float pad[5];
+} spt_instance;           /* 48 words = 192 B */
+
+/* ---- appearance ----------------------------------------------------------------*/
+
+/* Materials with scalar textures evaluate to a constant Bxdf variant, so the
+ * host resolves MaterialT::bxdf_context (src/material/{lambert,conductor,
+ * dielectric,pseudo}.rs) once: alpha = roughness^2, alpha < 1e-4 -> specular. */
+enum {
+    SPT_BXDF_LAMBERT = 0,              /* src/bxdf/lambert.rs               */
+    SPT_BXDF_MICROFACET_CONDUCTOR = 1, /* src/bxdf/microfacet_conductor.rs  */
+    SPT_BXDF_SPECULAR_CONDUCTOR = 2,   /* src/bxdf/specular_conductor.rs    */
+    SPT_BXDF_MICROFACET_DIELECTRIC = 3,/* src/bxdf/microfacet_dielectric.rs */
+    SPT_BXDF_SPECULAR_DIELECTRIC = 4,  /* src/bxdf/specular_dielectric.rs   */
+    SPT_BXDF_PSEUDO = 5                /* src/bxdf/pseudo.rs                */
+};
+typedef struct spt_material {
+    uint32_t bxdf;
+    float c0[3];     /* lambert: reflectance; conductor: ior (eta)         */
+    float c1[3];     /* conductor: ior_k                                   */
+    float ax, ay;    /* GGX roughness_x / roughness_y (already squared)    */
+    float ior;       /* dielectric: int_ior / ext_ior                      */
+    float pad[2];
+} spt_material;      /* 12 words */
+
+enum { SPT_SURF_DOUBLE_SIDED = 1u };
+typedef struct spt_surface {  /* src/core/surface.rs:14-22 (no maps: scalar-texture scope) */
+    uint32_t material;
+    uint32_t flags;
+    int32_t inside_medium;    /* medium index or -1 */
+    float emissive[3];
+    float pad[2];
+} spt_surface;                /* 8 words */
+
+typedef struct spt_medium {   /* src/medium/homogeneous.rs:11-15 */
+    float sigma_t[3];
+    float sigma_s[3];
+    float g;
+    float pad;
+} spt_medium;
+
+enum {
+    SPT_LIGHT_DIRECTIONAL = 0, /* src/light/directional.rs (direction stored normalised) */
+    SPT_LIGHT_POINT = 1,       /* src/light/point.rs       */
+    SPT_LIGHT_SPOT = 2,        /* src/light/spot.rs        */
+    SPT_LIGHT_SHAPE = 3,       /* src/light/shape_light.rs */
+    SPT_LIGHT_ENV = 4          /* src/light/environment.rs */
+};
+typedef struct spt_light {
+    uint32_t type;
+    float pos[3];        /* point/spot position                        */
+    float dir[3];        /* directional/spot direction                 */
+    float strength[3];
+    float cos_inner, cos_outer;
+    uint32_t instance;   /* SHAPE: instance index                      */
+    float power;         /* LightT::power() (alias-table input)        */
+    float pad[2];
+} spt_light;             /* 16 words */
+
+enum { SPT_LIGHT_SAMPLER_UNIFORM = 0, SPT_LIGHT_SAMPLER_POWER_IS = 1 };
+
+/* AliasTable (src/core/alias_table.rs:1-5): props / u / k, all length n. */
+typedef struct spt_alias_table {
+    uint32_t n;
+    const float* props;
+    const float* u;
+    const uint32_t* k;
+} spt_alias_table;
+
+typedef struct spt_env {      /* EnvLight (src/light/environment.rs:10-17) */
+    uint32_t width, height;   /* 0,0 = no environment */
+    const float* texels;      /* height*width RGB f32, row 0 = theta 0 */
+    float scale[3];
+    spt_alias_table alias;    /* n = width*height */
+} spt_env;
+
+enum { SPT_AGGREGATE_GROUP = 0, SPT_AGGREGATE_BVH = 1 };
+
+/* The flattened Scene (src/core/scene.rs:9-14 + everything it points to). */
+typedef struct spt_scene_desc {
+    uint32_t abi_version;          /* SPT_ABI_VERSION */
+    uint32_t aggregate;            /* SPT_AGGREGATE_*: GROUP skips the top-level box test
+                                      (src/primitive/group.rs:34-40) */
+    uint32_t n_tlas_nodes;  const spt_bvh_node* tlas_nodes;  /* leaves index instances */
+    uint32_t n_instances;   const spt_instance* instances;   /* in TLAS leaf order     */
+    uint32_t n_meshes;      const spt_mesh* meshes;
+    uint32_t n_blas_nodes;  const spt_bvh_node* blas_nodes;
+    uint32_t n_tris;        const spt_tri_pos* tri_pos;  const spt_tri_attr* tri_attr;
+    uint32_t n_spheres;     const spt_sphere* spheres;
+    uint32_t n_surfaces;    const spt_surface* surfaces;
+    uint32_t n_materials;   const spt_material* materials;
+    uint32_t n_mediums;     const spt_medium* mediums;
+    uint32_t n_lights;      const spt_light* lights;
+    uint32_t light_sampler;        /* SPT_LIGHT_SAMPLER_* */
+    int32_t env_light_index;       /* index of the ENV light in lights, -1 if none */
+    spt_alias_table light_alias;   /* POWER_IS only (n = n_lights) */
+    spt_env env;
+} spt_scene_desc;
+
+/* PerspectiveCamera after ::new (src/camera/perspective.rs:15-27). */
+typedef struct spt_camera {
+    float eye[3];
+    float forward[3];   /* normalised                  */
+    float up[3];        /* right x forward             */
+    float right[3];     /* normalize(forward x up_in)  */
+    float half_cot_half_fov;
+} spt_camera;
+
+enum { SPT_SAMPLER_RANDOM = 0, SPT_SAMPLER_JITTERED = 1, SPT_SAMPLER_RECURRENCE = 2 };
+
+/* PathTracer{max_depth, pixel_sampler, filter} + OutputConfig{width,height}
+ * (src/renderer/pt.rs:24-28, src/renderer/mod.rs:9-14) + the shard of the image
+ * this call renders. */
+typedef struct spt_render_params {
+    uint32_t width, height;        /* full image */
+    uint32_t spp;                  /* samples per pixel (jittered: division_x*division_y) */
+    uint32_t max_depth;
+    uint32_t sampler;              /* SPT_SAMPLER_* */
+    uint32_t division_x, division_y; /* jittered only */
+    uint64_t seed;
+    /* row-strip sharding: this call renders rows j with (j / strip_rows) % shard_count
+     * == shard_index; output rows are packed in increasing j.  shard_count=1 -> all. */
+    uint32_t shard_index, shard_count, strip_rows;
+    uint32_t samples_per_pass;     /* tuning: spp rendered per wavefront pass (0 = default) */
+    uint32_t flags;                /* SPT_RENDER_* */
+} spt_render_params;
+enum { SPT_RENDER_PROFILE = 1u /* time each kernel class with HIP events */ };
+
+#define SPT_N_KERNELS 6
+enum { SPT_K_PRIMARY = 0, SPT_K_SHADE = 1, SPT_K_SHADOW = 2, SPT_K_EXTEND = 3, SPT_K_RESOLVE = 4, SPT_K_OTHER = 5 };
+typedef struct spt_render_stats {
+    uint64_t samples;              /* camera samples traced = rows*width*spp               */
+    uint64_t segments_closest;     /* closest-hit ray segments (primary + extension)       */
+    uint64_t segments_shadow;      /* any-hit ray segments                                 */
+    double gpu_ms;                 /* HIP-event time of the whole call on the render stream */
+    double kernel_ms[SPT_N_KERNELS];      /* per kernel class (SPT_RENDER_PROFILE only)     */
+    uint32_t kernel_launches[SPT_N_KERNELS];
+} spt_render_stats;
+
+/* Closest-hit record: what BvhAccel/Group::intersect leave in `Intersection`
+ * (src/core/intersection.rs:6-18) before shading: t, who was hit, barycentrics. */
+typedef struct spt_hit {
+    float t;              /* f32::MAX on miss */
+    int32_t instance;     /* -1 on miss */
+    int32_t prim;         /* triangle index (absolute) or sphere index */
+    float v, w;           /* triangle barycentrics of p1, p2 (u = 1 - v - w) */
+} spt_hit;
+
+/* One ray: origin, t_min, direction, t_max (32 B). */
+typedef struct spt_ray {
+    float o[3]; float t_min;
+    float d[3]; float t_max;
+} spt_ray;
+
+typedef struct spt_scene spt_scene;   /* opaque: device-resident copy of a spt_scene_desc */
+
+spt_status spt_device_count(int32_t* count);
+/* Validates desc, copies it to HBM on `device` (SoA-repacked), owns the copy. */
+spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scene** out);
+void spt_scene_destroy(spt_scene* scene);
+
+/* The hot path: RendererT::render for one image shard.  rgb_mean_out receives
+ * shard_rows*width*3 f32 = per-pixel mean radiance (Film::filter_pixel with the
+ * box filter of radius <= 0.5, src/core/film.rs:71-91), row 0 = top.  Synchronous. */
+spt_status spt_render(const spt_scene* scene, const spt_camera* cam, const spt_render_params* params,
+                      float* rgb_mean_out, spt_render_stats* stats /* may be NULL */);
+/* Number of image rows spt_render writes for these params. */
+spt_status spt_shard_rows(const spt_render_params* params, uint32_t* rows);
+
+/* Seams below the renderer, for parity tests of rows a4/a6/a8/a9/a10:
+ * Primitive::intersect / intersect_test of the scene aggregate on caller rays. */
+spt_status spt_trace_closest(const spt_scene* scene, uint32_t n, const spt_ray* rays, spt_hit* hits);
+spt_status spt_trace_any(const spt_scene* scene, uint32_t n, const spt_ray* rays, uint8_t* occluded);
+
+const char* spt_last_error(void);
+uint32_t spt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPT_ABI_H */

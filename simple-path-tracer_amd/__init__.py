@@ -1,0 +1,421 @@
+"""simple-path-tracer hot path, MI355X-native — Python binding over the C ABIs.
+
+Mirrors the reference's host-side surface for the path
+(reference src/main.rs:43-66, src/loader/mod.rs:9-31, src/renderer/mod.rs:9-38):
+
+    scene    = load_scene("scene.json")          # loader::load_scene
+    renderer = load_renderer("pt.json")          # loader::load_renderer -> PathTracer
+    film     = renderer.render(scene, OutputConfig(width, height, output, camera))
+
+`render` runs the hand-written HIP kernels of libspt_hip.so.  There is no CPU
+fallback: if the library or a gfx950 device is missing the call raises.
+PyTorch is not involved in this module at all (ctypes + numpy only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+REPO_ROOT = os.path.dirname(_HERE)
+
+SPT_ABI_VERSION = 1
+SPT_LEAF_FLAG = 0x80000000
+
+STATUS_NAMES = {
+    0: "SPT_OK", 1: "SPT_ERR_INVALID_ARG", 2: "SPT_ERR_NO_DEVICE", 3: "SPT_ERR_HIP", 4: "SPT_ERR_UNSUPPORTED",
+    5: "SPT_ERR_OUT_OF_MEMORY", 100: "SPT_HOST_ERR_IO", 101: "SPT_HOST_ERR_PARSE", 102: "SPT_HOST_ERR_SCHEMA",
+    103: "SPT_HOST_ERR_UNSUPPORTED",
+}
+
+
+class SptError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, str(status)), message))
+        self.status = status
+        self.message = message
+
+
+# ---- ctypes mirrors of include/spt_abi.h ---------------------------------------------
+
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("a", C.c_uint32), ("bmax", C.c_float * 3), ("b", C.c_uint32)]
+
+
+class TriPos(C.Structure):
+    _fields_ = [("p0", C.c_float * 3), ("pad0", C.c_float), ("p1", C.c_float * 3), ("pad1", C.c_float),
+                ("p2", C.c_float * 3), ("pad2", C.c_float)]
+
+
+class TriAttr(C.Structure):
+    _fields_ = [("n", (C.c_float * 3) * 3), ("t", (C.c_float * 3) * 3), ("b", (C.c_float * 3) * 3),
+                ("uv", (C.c_float * 2) * 3), ("pad", C.c_float * 3)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("root", C.c_uint32), ("node_count", C.c_uint32), ("tri_first", C.c_uint32), ("tri_count", C.c_uint32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("inv", C.c_float * 12), ("fwd", C.c_float * 12), ("nrm", C.c_float * 9),
+                ("prim_type", C.c_uint32), ("prim_id", C.c_uint32), ("surface", C.c_uint32), ("light", C.c_int32),
+                ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("pad", C.c_float * 5)]
+
+
+class Material(C.Structure):
+    _fields_ = [("bxdf", C.c_uint32), ("c0", C.c_float * 3), ("c1", C.c_float * 3), ("ax", C.c_float),
+                ("ay", C.c_float), ("ior", C.c_float), ("pad", C.c_float * 2)]
+
+
+class Surface(C.Structure):
+    _fields_ = [("material", C.c_uint32), ("flags", C.c_uint32), ("inside_medium", C.c_int32),
+                ("emissive", C.c_float * 3), ("pad", C.c_float * 2)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("sigma_t", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("pad", C.c_float)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("pos", C.c_float * 3), ("dir", C.c_float * 3), ("strength", C.c_float * 3),
+                ("cos_inner", C.c_float), ("cos_outer", C.c_float), ("instance", C.c_uint32), ("power", C.c_float),
+                ("pad", C.c_float * 2)]
+
+
+class AliasTable(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("props", C.POINTER(C.c_float)), ("u", C.POINTER(C.c_float)),
+                ("k", C.POINTER(C.c_uint32))]
+
+
+class Env(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("texels", C.POINTER(C.c_float)),
+                ("scale", C.c_float * 3), ("alias", AliasTable)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("aggregate", C.c_uint32),
+        ("n_tlas_nodes", C.c_uint32), ("tlas_nodes", C.POINTER(BvhNode)),
+        ("n_instances", C.c_uint32), ("instances", C.POINTER(Instance)),
+        ("n_meshes", C.c_uint32), ("meshes", C.POINTER(Mesh)),
+        ("n_blas_nodes", C.c_uint32), ("blas_nodes", C.POINTER(BvhNode)),
+        ("n_tris", C.c_uint32), ("tri_pos", C.POINTER(TriPos)), ("tri_attr", C.POINTER(TriAttr)),
+        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere)),
+        ("n_surfaces", C.c_uint32), ("surfaces", C.POINTER(Surface)),
+        ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
+        ("n_mediums", C.c_uint32), ("mediums", C.POINTER(Medium)),
+        ("n_lights", C.c_uint32), ("lights", C.POINTER(Light)),
+        ("light_sampler", C.c_uint32), ("env_light_index", C.c_int32),
+        ("light_alias", AliasTable), ("env", Env),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("half_cot_half_fov", C.c_float)]
+
+
+SAMPLER_RANDOM, SAMPLER_JITTERED, SAMPLER_RECURRENCE = 0, 1, 2
+RENDER_PROFILE = 1
+N_KERNELS = 6
+KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other")
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
+                ("sampler", C.c_uint32), ("division_x", C.c_uint32), ("division_y", C.c_uint32),
+                ("seed", C.c_uint64), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("strip_rows", C.c_uint32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments_closest", C.c_uint64), ("segments_shadow", C.c_uint64),
+                ("gpu_ms", C.c_double), ("kernel_ms", C.c_double * N_KERNELS),
+                ("kernel_launches", C.c_uint32 * N_KERNELS)]
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("instance", "<i4"), ("prim", "<i4"), ("v", "<f4"), ("w", "<f4")])
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("t_min", "<f4"), ("d", "<f4", 3), ("t_max", "<f4")])
+
+
+# ---- library loading -----------------------------------------------------------------
+
+def _load(name: str) -> C.CDLL:
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise SptError(2 if "hip" in name else 100,
+                       "%s is not built (run `make` or `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_host_lib: Optional[C.CDLL] = None
+_hip_lib: Optional[C.CDLL] = None
+
+
+def host_lib() -> C.CDLL:
+    global _host_lib
+    if _host_lib is None:
+        lib = _load("libspt_host.so")
+        lib.spt_host_last_error.restype = C.c_char_p
+        lib.spt_host_load_scene.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.spt_host_scene_desc.argtypes = [C.c_void_p]
+        lib.spt_host_scene_desc.restype = C.POINTER(SceneDesc)
+        lib.spt_host_scene_camera.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Camera)]
+        lib.spt_host_scene_free.argtypes = [C.c_void_p]
+        lib.spt_host_scene_free.restype = None
+        lib.spt_host_load_renderer.argtypes = [C.c_char_p, C.POINTER(RenderParams), C.POINTER(C.c_float)]
+        lib.spt_host_film_to_rgb8.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.spt_host_film_to_rgb8.restype = None
+        lib.spt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.spt_host_read_exr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.POINTER(C.c_float))]
+        lib.spt_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.spt_host_free.argtypes = [C.c_void_p]
+        lib.spt_host_free.restype = None
+        _host_lib = lib
+    return _host_lib
+
+
+def hip_lib() -> C.CDLL:
+    """The product path.  Raises if libspt_hip.so is missing — never falls back."""
+    global _hip_lib
+    if _hip_lib is None:
+        lib = _load("libspt_hip.so")
+        lib.spt_last_error.restype = C.c_char_p
+        lib.spt_abi_version.restype = C.c_uint32
+        lib.spt_device_count.argtypes = [C.POINTER(C.c_int32)]
+        lib.spt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(C.c_void_p)]
+        lib.spt_scene_destroy.argtypes = [C.c_void_p]
+        lib.spt_scene_destroy.restype = None
+        lib.spt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
+                                   C.POINTER(RenderStats)]
+        lib.spt_shard_rows.argtypes = [C.POINTER(RenderParams), C.POINTER(C.c_uint32)]
+        lib.spt_trace_closest.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.spt_trace_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _hip_lib = lib
+    return _hip_lib
+
+
+def _check_host(status: int) -> None:
+    if status != 0:
+        raise SptError(status, host_lib().spt_host_last_error().decode("utf-8", "replace"))
+
+
+def _check_hip(status: int) -> None:
+    if status != 0:
+        raise SptError(status, hip_lib().spt_last_error().decode("utf-8", "replace"))
+
+
+# ---- host side: Scene / renderer loading -----------------------------------------------
+
+class Scene:
+    """Flattened scene (reference `Scene`, src/core/scene.rs:9-14) owned by libspt_host."""
+
+    def __init__(self, path: str):
+        self._h = C.c_void_p()
+        _check_host(host_lib().spt_host_load_scene(os.fspath(path).encode(), C.byref(self._h)))
+        self.path = os.fspath(path)
+        self._device_scenes = {}
+
+    @property
+    def desc(self) -> SceneDesc:
+        return host_lib().spt_host_scene_desc(self._h).contents
+
+    def get_camera(self, name: Optional[str] = None) -> Camera:
+        cam = Camera()
+        _check_host(host_lib().spt_host_scene_camera(self._h, name.encode() if name else None, C.byref(cam)))
+        return cam
+
+    def array(self, field: str) -> np.ndarray:
+        """Copy of one desc array as a structured / float numpy array (for tests)."""
+        d = self.desc
+        table = {
+            "tlas_nodes": (d.tlas_nodes, d.n_tlas_nodes, BvhNode), "blas_nodes": (d.blas_nodes, d.n_blas_nodes, BvhNode),
+            "instances": (d.instances, d.n_instances, Instance), "meshes": (d.meshes, d.n_meshes, Mesh),
+            "tri_pos": (d.tri_pos, d.n_tris, TriPos), "tri_attr": (d.tri_attr, d.n_tris, TriAttr),
+            "spheres": (d.spheres, d.n_spheres, Sphere), "surfaces": (d.surfaces, d.n_surfaces, Surface),
+            "materials": (d.materials, d.n_materials, Material), "mediums": (d.mediums, d.n_mediums, Medium),
+            "lights": (d.lights, d.n_lights, Light),
+        }
+        ptr, n, ty = table[field]
+        if n == 0:
+            return np.zeros((0,), dtype=np.dtype(ty))
+        buf = C.string_at(ptr, n * C.sizeof(ty))
+        return np.frombuffer(buf, dtype=np.dtype(ty)).copy()
+
+    def device_scene(self, device: int = 0) -> "DeviceScene":
+        if device not in self._device_scenes:
+            self._device_scenes[device] = DeviceScene(self, device)
+        return self._device_scenes[device]
+
+    def close(self) -> None:
+        for ds in self._device_scenes.values():
+            ds.close()
+        self._device_scenes.clear()
+        if self._h:
+            host_lib().spt_host_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_scene(path: str) -> Scene:
+    """loader::load_scene (src/loader/mod.rs:20-31)."""
+    return Scene(path)
+
+
+class DeviceScene:
+    """HBM-resident copy of a Scene (spt_scene_create)."""
+
+    def __init__(self, scene: Scene, device: int = 0):
+        self._h = C.c_void_p()
+        self.scene = scene
+        self.device = device
+        desc = scene.desc
+        _check_hip(hip_lib().spt_scene_create(C.byref(desc), device, C.byref(self._h)))
+
+    def trace_closest(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        _check_hip(hip_lib().spt_trace_closest(self._h, rays.shape[0], rays.ctypes.data, hits.ctypes.data))
+        return hits
+
+    def trace_any(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        occ = np.zeros(rays.shape[0], dtype=np.uint8)
+        _check_hip(hip_lib().spt_trace_any(self._h, rays.shape[0], rays.ctypes.data, occ.ctypes.data))
+        return occ
+
+    def close(self) -> None:
+        if self._h:
+            hip_lib().spt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class OutputConfig:
+    """reference src/renderer/mod.rs:9-14"""
+    width: int = 512
+    height: int = 512
+    output_filename: Optional[str] = None
+    used_camera_name: Optional[str] = None
+
+
+def shard_rows(height: int, shard_index: int, shard_count: int, strip_rows: int) -> np.ndarray:
+    """Image rows (top = 0) rendered by one shard: interleaved strips of `strip_rows` rows."""
+    j = np.arange(height)
+    return j[(j // strip_rows) % shard_count == shard_index]
+
+
+class PathTracer:
+    """reference PathTracer{max_depth, pixel_sampler, filter} (src/renderer/pt.rs:24-37)."""
+
+    def __init__(self, max_depth: int = 8, sampler: int = SAMPLER_RECURRENCE, spp: int = 256,
+                 division_x: int = 0, division_y: int = 0, filter_radius: float = 0.5, seed: int = 1):
+        self.max_depth = max_depth
+        self.sampler = sampler
+        self.spp = spp
+        self.division_x = division_x
+        self.division_y = division_y
+        self.filter_radius = filter_radius
+        self.seed = seed
+        self.last_stats: Optional[RenderStats] = None
+
+    def params(self, width: int, height: int, shard_index: int = 0, shard_count: int = 1, strip_rows: int = 16,
+               samples_per_pass: int = 0, flags: int = 0) -> RenderParams:
+        if self.filter_radius > 0.5:
+            # Film::filter_pixel sums unweighted colours over neighbours for radius > 0.5
+            # (reference quirk Q1, src/core/film.rs:82-90); only the box radius <= 0.5 is in scope.
+            raise SptError(4, "box filter radius > 0.5 is outside the hot-path scope")
+        p = RenderParams()
+        p.width, p.height, p.spp, p.max_depth = width, height, self.spp, self.max_depth
+        p.sampler, p.division_x, p.division_y = self.sampler, self.division_x, self.division_y
+        p.seed = self.seed
+        p.shard_index, p.shard_count, p.strip_rows = shard_index, shard_count, strip_rows
+        p.samples_per_pass, p.flags = samples_per_pass, flags
+        return p
+
+    def render_shard(self, scene: Scene, config: OutputConfig, device: int = 0, shard_index: int = 0,
+                     shard_count: int = 1, strip_rows: int = 16, samples_per_pass: int = 0,
+                     profile: bool = False) -> np.ndarray:
+        """Mean radiance of this shard's rows, shape (rows, width, 3) f32, via the HIP path."""
+        ds = scene.device_scene(device)
+        cam = scene.get_camera(config.used_camera_name)
+        p = self.params(config.width, config.height, shard_index, shard_count, strip_rows, samples_per_pass,
+                        RENDER_PROFILE if profile else 0)
+        rows = C.c_uint32()
+        _check_hip(hip_lib().spt_shard_rows(C.byref(p), C.byref(rows)))
+        out = np.zeros((rows.value, config.width, 3), dtype=np.float32)
+        stats = RenderStats()
+        _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(stats)))
+        self.last_stats = stats
+        return out
+
+    def render(self, scene: Scene, config: OutputConfig, device: int = 0) -> np.ndarray:
+        """RendererT::render (src/renderer/pt.rs:237-296): full image on one GPU; writes the PNG
+        when config.output_filename is set and returns the float film (H, W, 3)."""
+        film = self.render_shard(scene, config, device)
+        if config.output_filename:
+            write_png(config.output_filename, film)
+        return film
+
+
+def load_renderer(path: str, seed: int = 1) -> PathTracer:
+    """loader::load_renderer (src/loader/json.rs:19-51)."""
+    p = RenderParams()
+    radius = C.c_float()
+    _check_host(host_lib().spt_host_load_renderer(os.fspath(path).encode(), C.byref(p), C.byref(radius)))
+    return PathTracer(p.max_depth, p.sampler, p.spp, p.division_x, p.division_y, radius.value, seed)
+
+
+def film_to_rgb8(film: np.ndarray) -> np.ndarray:
+    """color_to_rgb (src/core/film.rs:94-99): truncating, no gamma."""
+    film = np.ascontiguousarray(film, dtype=np.float32)
+    out = np.zeros(film.shape, dtype=np.uint8)
+    host_lib().spt_host_film_to_rgb8(film.ctypes.data, film.size // 3, out.ctypes.data)
+    return out
+
+
+def write_png(path: str, film: np.ndarray) -> None:
+    rgb8 = film_to_rgb8(film)
+    h, w = rgb8.shape[:2]
+    _check_host(host_lib().spt_host_write_png(os.fspath(path).encode(), rgb8.ctypes.data, w, h))
+
+
+def read_exr(path: str) -> np.ndarray:
+    w, h = C.c_uint32(), C.c_uint32()
+    ptr = C.POINTER(C.c_float)()
+    _check_host(host_lib().spt_host_read_exr(os.fspath(path).encode(), C.byref(w), C.byref(h), C.byref(ptr)))
+    arr = np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+    host_lib().spt_host_free(ptr)
+    return arr
+
+
+def write_exr(path: str, rgb: np.ndarray) -> None:
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    _check_host(host_lib().spt_host_write_exr(os.fspath(path).encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
+
+
+def device_count() -> int:
+    n = C.c_int32()
+    _check_hip(hip_lib().spt_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,46 @@
+// Owning storage behind a spt_scene_desc (the arrays a Rust `Scene::flatten()`
+// would own on the reference side).
+#pragma once
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/spt_host.h"
+
+namespace spt_host {
+
+struct HostError {
+    spt_status code;
+    std::string msg;
+    HostError(spt_status c, std::string m) : code(c), msg(std::move(m)) {}
+};
+
+struct HostScene {
+    std::vector<spt_bvh_node> tlas_nodes, blas_nodes;
+    std::vector<spt_instance> instances;
+    std::vector<spt_mesh> meshes;
+    std::vector<spt_tri_pos> tri_pos;
+    std::vector<spt_tri_attr> tri_attr;
+    std::vector<spt_sphere> spheres;
+    std::vector<spt_surface> surfaces;
+    std::vector<spt_material> materials;
+    std::vector<spt_medium> mediums;
+    std::vector<spt_light> lights;
+    std::vector<float> light_props, light_u;
+    std::vector<uint32_t> light_k;
+    std::vector<float> env_texels, env_props, env_u;
+    std::vector<uint32_t> env_k;
+    uint32_t env_w = 0, env_h = 0;
+    float env_scale[3] = {1, 1, 1};
+    uint32_t aggregate = SPT_AGGREGATE_BVH, light_sampler = SPT_LIGHT_SAMPLER_UNIFORM;
+    int32_t env_light_index = -1;
+    std::vector<spt_camera> cameras;
+    std::map<std::string, size_t> camera_index;
+    spt_scene_desc desc;
+    void finalize_desc();
+};
+
+HostScene* load_scene_file(const std::string& path);
+
+}  // namespace spt_host

@@ -1,0 +1,275 @@
+// Image I/O for the host side: PNG write-out of the u8 film (image.save,
+// reference src/renderer/pt.rs:290-294) and a minimal OpenEXR scanline
+// reader/writer for `environment {type: "exr"}` (get_exr_image, reference
+// src/core/loader.rs:374-390 reads the first RGBA layer as f32).
+// Supported EXR subset: single-part scanline files, channels R,G,B (A ignored) of
+// type HALF or FLOAT, compression NONE / ZIPS / ZIP, any line order.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_scene.hpp"
+
+namespace spt_host {
+void set_error(const std::string& m);
+}
+using spt_host::HostError;
+
+namespace {
+
+float half_to_float(uint16_t h) {
+    uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u, u;
+    if (e == 0) {
+        if (m == 0) {
+            u = s;
+        } else {
+            int sh = 0;
+            while (!(m & 1024u)) { m <<= 1; ++sh; }
+            m &= 1023u;
+            u = s | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13);
+        }
+    } else if (e == 31) {
+        u = s | 0x7f800000u | (m << 13);
+    } else {
+        u = s | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Reader {
+    const std::vector<uint8_t>& d;
+    size_t p = 0;
+    explicit Reader(const std::vector<uint8_t>& data) : d(data) {}
+    void need(size_t n) { if (p + n > d.size()) throw HostError(SPT_HOST_ERR_PARSE, "exr: truncated file"); }
+    uint8_t u8() { need(1); return d[p++]; }
+    int32_t i32() { need(4); int32_t v; std::memcpy(&v, &d[p], 4); p += 4; return v; }
+    uint64_t u64() { need(8); uint64_t v; std::memcpy(&v, &d[p], 8); p += 8; return v; }
+    std::string cstr() {
+        std::string s;
+        while (true) { uint8_t c = u8(); if (!c) break; s += (char)c; }
+        return s;
+    }
+};
+
+void put_u32(std::vector<uint8_t>& o, uint32_t v) { for (int i = 0; i < 4; ++i) o.push_back((uint8_t)(v >> (8 * i))); }
+void put_u64(std::vector<uint8_t>& o, uint64_t v) { for (int i = 0; i < 8; ++i) o.push_back((uint8_t)(v >> (8 * i))); }
+void put_str(std::vector<uint8_t>& o, const char* s) { while (*s) o.push_back((uint8_t)*s++); o.push_back(0); }
+void put_f32(std::vector<uint8_t>& o, float f) { uint32_t u; std::memcpy(&u, &f, 4); put_u32(o, u); }
+void put_attr(std::vector<uint8_t>& o, const char* name, const char* type, const std::vector<uint8_t>& data) {
+    put_str(o, name); put_str(o, type); put_u32(o, (uint32_t)data.size());
+    o.insert(o.end(), data.begin(), data.end());
+}
+
+}  // namespace
+
+extern "C" {
+
+void spt_host_free(void* p) { std::free(p); }
+
+spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height, float** rgb_out) {
+    try {
+        if (!path || !width || !height || !rgb_out) throw HostError(SPT_ERR_INVALID_ARG, "read_exr: null argument");
+        FILE* f = std::fopen(path, "rb");
+        if (!f) throw HostError(SPT_HOST_ERR_IO, std::string("cannot open EXR '") + path + "'");
+        std::vector<uint8_t> data;
+        uint8_t buf[65536];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
+        std::fclose(f);
+        Reader r(data);
+        if (r.i32() != 20000630) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad magic");
+        int32_t version = r.i32();
+        if (version & 0x1A00) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: tiled / deep / multipart files are not supported");
+        struct Chan { std::string name; int32_t type; };
+        std::vector<Chan> chans;
+        int compression = -1;
+        int32_t dw[4] = {0, 0, -1, -1};
+        while (true) {
+            std::string name = r.cstr();
+            if (name.empty()) break;
+            std::string type = r.cstr();
+            int32_t size = r.i32();
+            size_t end = r.p + (size_t)size;
+            r.need((size_t)size);
+            if (name == "channels") {
+                while (true) {
+                    std::string cn = r.cstr();
+                    if (cn.empty()) break;
+                    Chan c; c.name = cn; c.type = r.i32();
+                    r.p += 4;  // pLinear + reserved
+                    int32_t xs = r.i32(), ys = r.i32();
+                    if (xs != 1 || ys != 1) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: subsampled channels are not supported");
+                    chans.push_back(c);
+                }
+            } else if (name == "compression") {
+                compression = r.u8();
+            } else if (name == "dataWindow") {
+                for (int i = 0; i < 4; ++i) dw[i] = r.i32();
+            }
+            r.p = end;
+        }
+        if (compression != 0 && compression != 2 && compression != 3)
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: only NONE / ZIPS / ZIP compression is supported");
+        int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
+        if (w <= 0 || h <= 0 || w > 65536 || h > 65536) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad dataWindow");
+        int lines_per_block = (compression == 3) ? 16 : 1;
+        int64_t n_blocks = (h + lines_per_block - 1) / lines_per_block;
+        size_t row_bytes = 0;
+        std::vector<size_t> chan_off(chans.size());
+        int idx[3] = {-1, -1, -1};
+        for (size_t c = 0; c < chans.size(); ++c) {
+            chan_off[c] = row_bytes;
+            if (chans[c].type != 1 && chans[c].type != 2 && chans[c].type != 0) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad channel type");
+            row_bytes += (size_t)w * (chans[c].type == 1 ? 2 : 4);
+            if (chans[c].name == "R") idx[0] = (int)c;
+            if (chans[c].name == "G") idx[1] = (int)c;
+            if (chans[c].name == "B") idx[2] = (int)c;
+        }
+        if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: needs R, G and B channels");
+        for (int k = 0; k < 3; ++k)
+            if (chans[idx[k]].type == 0) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: UINT colour channels are not supported");
+        std::vector<uint64_t> offsets((size_t)n_blocks);
+        for (auto& o : offsets) o = r.u64();
+        float* out = (float*)std::malloc((size_t)w * h * 3 * sizeof(float));
+        if (!out) throw HostError(SPT_ERR_OUT_OF_MEMORY, "exr: out of memory");
+        try {
+            std::vector<uint8_t> raw, tmp;
+            for (int64_t b = 0; b < n_blocks; ++b) {
+                r.p = (size_t)offsets[(size_t)b];
+                int32_t y0 = r.i32() - dw[1];
+                int32_t size = r.i32();
+                if (size < 0 || y0 < 0 || y0 >= h) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad chunk");
+                r.need((size_t)size);
+                int64_t lines = std::min<int64_t>(lines_per_block, h - y0);
+                size_t want = row_bytes * (size_t)lines;
+                raw.resize(want);
+                if (compression == 0 || (size_t)size == want) {
+                    if ((size_t)size != want) throw HostError(SPT_HOST_ERR_PARSE, "exr: chunk size mismatch");
+                    std::memcpy(raw.data(), &data[r.p], want);
+                } else {
+                    tmp.resize(want);
+                    uLongf dl = (uLongf)want;
+                    if (uncompress(tmp.data(), &dl, &data[r.p], (uLong)size) != Z_OK || dl != want)
+                        throw HostError(SPT_HOST_ERR_PARSE, "exr: zlib inflate failed");
+                    for (size_t i = 1; i < want; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);
+                    size_t half = (want + 1) / 2;
+                    for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+                }
+                for (int64_t l = 0; l < lines; ++l) {
+                    const uint8_t* row = raw.data() + row_bytes * (size_t)l;
+                    for (int k = 0; k < 3; ++k) {
+                        const Chan& c = chans[idx[k]];
+                        const uint8_t* src = row + chan_off[idx[k]];
+                        for (int64_t x = 0; x < w; ++x) {
+                            float v;
+                            if (c.type == 1) { uint16_t hv; std::memcpy(&hv, src + 2 * x, 2); v = half_to_float(hv); }
+                            else std::memcpy(&v, src + 4 * x, 4);
+                            out[((size_t)(y0 + l) * w + x) * 3 + k] = v;
+                        }
+                    }
+                }
+            }
+        } catch (...) {
+            std::free(out);
+            throw;
+        }
+        *width = (uint32_t)w; *height = (uint32_t)h; *rgb_out = out;
+        return SPT_OK;
+    } catch (const HostError& e) {
+        spt_host::set_error(e.msg);
+        return e.code;
+    }
+}
+
+spt_status spt_host_write_exr(const char* path, const float* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || !width || !height) { spt_host::set_error("write_exr: bad argument"); return SPT_ERR_INVALID_ARG; }
+    std::vector<uint8_t> o;
+    put_u32(o, 20000630u);
+    put_u32(o, 2u);
+    {
+        std::vector<uint8_t> ch;
+        for (const char* n : {"B", "G", "R"}) {
+            put_str(ch, n); put_u32(ch, 2u); put_u32(ch, 0u); put_u32(ch, 1u); put_u32(ch, 1u);
+        }
+        ch.push_back(0);
+        put_attr(o, "channels", "chlist", ch);
+    }
+    put_attr(o, "compression", "compression", {0});
+    std::vector<uint8_t> box;
+    put_u32(box, 0); put_u32(box, 0); put_u32(box, width - 1); put_u32(box, height - 1);
+    put_attr(o, "dataWindow", "box2i", box);
+    put_attr(o, "displayWindow", "box2i", box);
+    put_attr(o, "lineOrder", "lineOrder", {0});
+    { std::vector<uint8_t> v; put_f32(v, 1.0f); put_attr(o, "pixelAspectRatio", "float", v); }
+    { std::vector<uint8_t> v; put_f32(v, 0.0f); put_f32(v, 0.0f); put_attr(o, "screenWindowCenter", "v2f", v); }
+    { std::vector<uint8_t> v; put_f32(v, 1.0f); put_attr(o, "screenWindowWidth", "float", v); }
+    o.push_back(0);
+    size_t row = (size_t)width * 12;
+    uint64_t first = o.size() + (uint64_t)height * 8;
+    for (uint32_t y = 0; y < height; ++y) put_u64(o, first + (uint64_t)y * (8 + row));
+    for (uint32_t y = 0; y < height; ++y) {
+        put_u32(o, y);
+        put_u32(o, (uint32_t)row);
+        for (int c = 2; c >= 0; --c)  // B, G, R planes
+            for (uint32_t x = 0; x < width; ++x) put_f32(o, rgb[((size_t)y * width + x) * 3 + c]);
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { spt_host::set_error(std::string("cannot write '") + path + "'"); return SPT_HOST_ERR_IO; }
+    size_t wr = std::fwrite(o.data(), 1, o.size(), f);
+    std::fclose(f);
+    if (wr != o.size()) { spt_host::set_error("short write"); return SPT_HOST_ERR_IO; }
+    return SPT_OK;
+}
+
+void spt_host_film_to_rgb8(const float* rgb_mean, uint64_t n_pixels, uint8_t* rgb8_out) {
+    for (uint64_t i = 0; i < n_pixels * 3; ++i) {
+        float c = rgb_mean[i] * 255.0f;
+        // Rust clamp keeps NaN, and `NaN as u8` is 0
+        float cl = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
+        rgb8_out[i] = (cl != cl) ? 0 : (uint8_t)cl;
+    }
+}
+
+spt_status spt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!path || !rgb8 || !width || !height) { spt_host::set_error("write_png: bad argument"); return SPT_ERR_INVALID_ARG; }
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)height * (1 + (size_t)width * 3));
+    for (uint32_t y = 0; y < height; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb8 + (size_t)y * width * 3, rgb8 + (size_t)(y + 1) * width * 3);
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { spt_host::set_error("png: deflate failed"); return SPT_HOST_ERR_IO; }
+    comp.resize(clen);
+    std::vector<uint8_t> o = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    auto be32 = [&](std::vector<uint8_t>& v, uint32_t x) { for (int i = 3; i >= 0; --i) v.push_back((uint8_t)(x >> (8 * i))); };
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& d) {
+        be32(o, (uint32_t)d.size());
+        std::vector<uint8_t> td(type, type + 4);
+        td.insert(td.end(), d.begin(), d.end());
+        o.insert(o.end(), td.begin(), td.end());
+        be32(o, (uint32_t)crc32(0L, td.data(), (uInt)td.size()));
+    };
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, width); be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk("IHDR", ihdr);
+    chunk("IDAT", comp);
+    chunk("IEND", {});
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { spt_host::set_error(std::string("cannot write '") + path + "'"); return SPT_HOST_ERR_IO; }
+    size_t wr = std::fwrite(o.data(), 1, o.size(), f);
+    std::fclose(f);
+    if (wr != o.size()) { spt_host::set_error("short write"); return SPT_HOST_ERR_IO; }
+    return SPT_OK;
+}
+
+}  // extern "C"

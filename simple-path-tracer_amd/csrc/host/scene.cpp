@@ -1,0 +1,924 @@
+// Scene JSON -> flattened spt_scene_desc.
+//
+// Host-side counterpart of the reference's loader + scene assembly:
+//   src/loader/json.rs:53-242            section order, object | array | external-file values
+//   src/core/loader.rs:286-305,404-438   typed getters (Int != Float), unused-key warnings
+//   src/core/scene_resources.rs:85-168   aggregate, light list, ShapeLight per emissive instance
+//   src/primitive/instance.rs:35-85      T * Rz * Rx * Ry * S * M transform composition
+//   src/primitive/triangle.rs:57-108,339-388  OBJ -> MeshVertex, tangents
+// The object graph is not kept: everything ends up in the POD arrays of spt_abi.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../../include/spt_host.h"
+#include "bvh.hpp"
+#include "hmath.hpp"
+#include "host_scene.hpp"
+#include "json.hpp"
+
+namespace spt_host {
+
+namespace {
+
+bool g_verbose() {
+    static int v = -1;
+    if (v < 0) v = std::getenv("SPT_LOG") ? 1 : 0;
+    return v == 1;
+}
+void warn(const std::string& m) {
+    if (g_verbose()) std::fprintf(stderr, "[spt warn] %s\n", m.c_str());
+}
+
+std::string with_file_name(const std::string& base, const std::string& file) {
+    size_t p = base.find_last_of('/');
+    if (p == std::string::npos) return file;
+    return base.substr(0, p + 1) + file;
+}
+
+std::string read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw HostError(SPT_HOST_ERR_IO, "cannot open '" + path + "'");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+JsonValue parse_json_file(const std::string& path) {
+    std::string text = read_file(path);
+    try {
+        return JsonParser(text).parse();
+    } catch (const std::runtime_error& e) {
+        throw HostError(SPT_HOST_ERR_PARSE, path + ": " + e.what());
+    }
+}
+
+// InputParams (src/core/loader.rs:11-16): typed access + visited-key tracking.
+class Params {
+   public:
+    Params(const JsonValue& v, std::string base_path) : base_(std::move(base_path)) {
+        if (v.kind != JsonValue::Object) throw HostError(SPT_HOST_ERR_SCHEMA, "expected a JSON object");
+        for (auto& kv : v.obj) {
+            if (kv.second.kind == JsonValue::Null)
+                throw HostError(SPT_HOST_ERR_SCHEMA, "can't convert to InputParamsValue from null json");
+            if (kv.second.kind == JsonValue::Object)
+                throw HostError(SPT_HOST_ERR_SCHEMA, "can't convert to InputParamsValue from object json");
+            vals_[kv.first] = &kv.second;
+        }
+    }
+    void set_name(const std::string& n) { name_ = n; }
+    const std::string& name() const { return name_; }
+    bool contains(const std::string& k) const { return vals_.count(k) != 0; }
+
+    std::string get_str(const std::string& k) {
+        const JsonValue* v = find(k);
+        if (v->kind != JsonValue::String) bad(k, "string");
+        visited_.insert(k);
+        return v->s;
+    }
+    float get_float(const std::string& k) {
+        const JsonValue* v = find(k);
+        if (v->kind != JsonValue::Float) bad(k, "float");  // Int is NOT accepted (loader.rs:286-299)
+        visited_.insert(k);
+        return (float)v->f;
+    }
+    float get_float_or(const std::string& k, float fb) {
+        auto it = vals_.find(k);
+        if (it == vals_.end() || it->second->kind != JsonValue::Float) return fb;
+        visited_.insert(k);
+        return (float)it->second->f;
+    }
+    int32_t get_int(const std::string& k) {
+        const JsonValue* v = find(k);
+        if (v->kind != JsonValue::Int) bad(k, "integer");
+        visited_.insert(k);
+        return (int32_t)v->i;
+    }
+    bool get_bool_or(const std::string& k, bool fb) {
+        auto it = vals_.find(k);
+        if (it == vals_.end() || it->second->kind != JsonValue::Bool) return fb;
+        visited_.insert(k);
+        return it->second->b;
+    }
+    V3 get_float3(const std::string& k) {
+        const JsonValue* v = find(k);
+        V3 out;
+        if (!float_vec(v, 3, &out.x)) bad(k, "array with 3 floats");
+        visited_.insert(k);
+        return out;
+    }
+    V3 get_float3_or(const std::string& k, V3 fb) {
+        auto it = vals_.find(k);
+        V3 out;
+        if (it == vals_.end() || !float_vec(it->second, 3, &out.x)) return fb;
+        visited_.insert(k);
+        return out;
+    }
+    // get_matrix (loader.rs:307-335): 16 values column-major; non-Float entries keep identity.
+    Affine get_matrix(const std::string& k) {
+        const JsonValue* v = find(k);
+        if (v->kind != JsonValue::Array) bad(k, "an array");
+        if (v->arr.size() != 16) bad(k, "an array of 16 floats");
+        float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int i = 0; i < 16; ++i)
+            if (v->arr[i].kind == JsonValue::Float) m[i] = (float)v->arr[i].f;
+        visited_.insert(k);
+        Affine a;  // Affine3A::from_mat4: upper 3x3 + translation column
+        a.m.c0 = {m[0], m[1], m[2]};
+        a.m.c1 = {m[4], m[5], m[6]};
+        a.m.c2 = {m[8], m[9], m[10]};
+        a.t = {m[12], m[13], m[14]};
+        return a;
+    }
+    std::string get_file_path(const std::string& k) { return with_file_name(base_, get_str(k)); }
+    size_t num_unused() const {
+        size_t n = 0;
+        for (auto& kv : vals_)
+            if (kv.first.rfind("#", 0) != 0 && !visited_.count(kv.first)) ++n;
+        return n;
+    }
+    void check_unused() const {
+        for (auto& kv : vals_)
+            if (kv.first.rfind("#", 0) != 0 && !visited_.count(kv.first)) warn(name_ + " - unused key '" + kv.first + "'");
+    }
+    void mark(const std::string& k) { visited_.insert(k); }
+
+   private:
+    std::map<std::string, const JsonValue*> vals_;
+    std::set<std::string> visited_;
+    std::string name_ = "?";
+    std::string base_;
+
+    const JsonValue* find(const std::string& k) {
+        auto it = vals_.find(k);
+        if (it == vals_.end()) throw HostError(SPT_HOST_ERR_SCHEMA, name_ + " - there is no '" + k + "' field");
+        return it->second;
+    }
+    [[noreturn]] void bad(const std::string& k, const char* hint) {
+        throw HostError(SPT_HOST_ERR_SCHEMA, name_ + " - '" + k + "' should be " + hint);
+    }
+    static bool float_vec(const JsonValue* v, size_t n, float* out) {
+        if (v->kind != JsonValue::Array || v->arr.size() != n) return false;
+        for (size_t i = 0; i < n; ++i) {
+            if (v->arr[i].kind != JsonValue::Float) return false;
+            out[i] = (float)v->arr[i].f;
+        }
+        return true;
+    }
+};
+
+float luminance(V3 c) { return 0.299f * c.x + 0.587f * c.y + 0.114f * c.z; }
+
+float srgb_to_linear(float s) {  // src/texture/srgb_tex.rs
+    if (s <= 0.04045f) return s / 12.92f;
+    return std::pow((s + 0.055f) / 1.055f, 2.4f);
+}
+
+struct ObjMesh {
+    std::vector<V3> pos, nrm, tan, bit;
+    std::vector<float> uv;  // 2 per vertex
+    std::vector<uint32_t> idx;
+};
+
+// tobj::load_obj with triangulate + single_index (src/primitive/triangle.rs:57-63):
+// each distinct (v, vt, vn) tuple becomes one vertex in first-seen order; polygons
+// are fanned.  All models of the file are merged into one vertex/index list.
+ObjMesh load_obj(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw HostError(SPT_HOST_ERR_IO, "cannot open OBJ '" + path + "'");
+    std::vector<V3> v, vn;
+    std::vector<std::pair<float, float>> vt;
+    ObjMesh m;
+    std::map<std::array<int, 3>, uint32_t> remap;
+    bool any_vt = false, any_vn = false;
+    std::vector<std::array<int, 3>> corners;
+    std::string line;
+    struct Face { std::vector<std::array<int, 3>> c; };
+    std::vector<Face> faces;
+    while (std::getline(f, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag)) continue;
+        if (tag == "v") {
+            V3 p; ls >> p.x >> p.y >> p.z; v.push_back(p);
+        } else if (tag == "vn") {
+            V3 p; ls >> p.x >> p.y >> p.z; vn.push_back(p);
+        } else if (tag == "vt") {
+            float a = 0, b = 0; ls >> a >> b; vt.emplace_back(a, b);
+        } else if (tag == "f") {
+            Face face;
+            std::string tok;
+            while (ls >> tok) {
+                std::array<int, 3> c = {0, 0, 0};  // 1-based, 0 = absent
+                int field = 0;
+                std::string cur;
+                auto flush = [&]() {
+                    if (!cur.empty() && field < 3) c[field] = std::atoi(cur.c_str());
+                    cur.clear();
+                };
+                for (char ch : tok) {
+                    if (ch == '/') { flush(); ++field; } else cur += ch;
+                }
+                flush();
+                if (c[0] < 0) c[0] = (int)v.size() + c[0] + 1;
+                if (c[1] < 0) c[1] = (int)vt.size() + c[1] + 1;
+                if (c[2] < 0) c[2] = (int)vn.size() + c[2] + 1;
+                if (c[0] <= 0 || c[0] > (int)v.size()) throw HostError(SPT_HOST_ERR_PARSE, path + ": face index out of range");
+                if (c[1] > (int)vt.size() || c[2] > (int)vn.size()) throw HostError(SPT_HOST_ERR_PARSE, path + ": face index out of range");
+                if (c[1] > 0) any_vt = true;
+                if (c[2] > 0) any_vn = true;
+                face.c.push_back(c);
+            }
+            if (face.c.size() >= 3) faces.push_back(std::move(face));
+        }
+    }
+    auto vertex_of = [&](const std::array<int, 3>& c) -> uint32_t {
+        auto it = remap.find(c);
+        if (it != remap.end()) return it->second;
+        uint32_t id = (uint32_t)m.pos.size();
+        remap[c] = id;
+        m.pos.push_back(v[c[0] - 1]);
+        // MeshVertex::default: normal Z, texcoords 0, tangent X, bitangent Y (triangle.rs:29-38)
+        m.nrm.push_back((any_vn && c[2] > 0) ? vn[c[2] - 1] : V3{0, 0, 1});
+        if (any_vt && c[1] > 0) { m.uv.push_back(vt[c[1] - 1].first); m.uv.push_back(vt[c[1] - 1].second); }
+        else { m.uv.push_back(0); m.uv.push_back(0); }
+        m.tan.push_back({1, 0, 0});
+        m.bit.push_back({0, 1, 0});
+        return id;
+    };
+    for (auto& face : faces)
+        for (size_t k = 1; k + 1 < face.c.size(); ++k) {
+            m.idx.push_back(vertex_of(face.c[0]));
+            m.idx.push_back(vertex_of(face.c[k]));
+            m.idx.push_back(vertex_of(face.c[k + 1]));
+        }
+    return m;
+}
+
+// TriMesh::calc_tangents (src/primitive/triangle.rs:339-388)
+void calc_tangents(ObjMesh& m) {
+    size_t nv = m.pos.size();
+    std::vector<V3> ts(nv), bs(nv);
+    std::vector<int> deg(nv, 0);
+    for (size_t t = 0; t + 2 < m.idx.size(); t += 3) {
+        uint32_t i0 = m.idx[t], i1 = m.idx[t + 1], i2 = m.idx[t + 2];
+        V3 e1 = m.pos[i1] - m.pos[i0], e2 = m.pos[i2] - m.pos[i0];
+        float u1x = m.uv[2 * i1] - m.uv[2 * i0], u1y = m.uv[2 * i1 + 1] - m.uv[2 * i0 + 1];
+        float u2x = m.uv[2 * i2] - m.uv[2 * i0], u2y = m.uv[2 * i2 + 1] - m.uv[2 * i0 + 1];
+        float det = u1x * u2y - u1y * u2x;
+        if (det != 0.0f) {
+            det = 1.0f / det;
+            V3 tg = normalize((e1 * u2y - e2 * u1y) * det);
+            V3 bt = normalize((e2 * u1x - e1 * u2x) * det);
+            for (uint32_t i : {i0, i1, i2}) { ts[i] = ts[i] + tg; bs[i] = bs[i] + bt; deg[i]++; }
+        }
+    }
+    for (size_t i = 0; i < nv; ++i)
+        if (deg[i] != 0) {
+            float inv = 1.0f / (float)deg[i];
+            m.tan[i] = normalize(ts[i] * inv);
+            m.bit[i] = normalize(bs[i] * inv);
+        }
+}
+
+struct PrimRec { uint32_t type; uint32_t id; Box box; };
+struct SurfaceRec { uint32_t index; bool emissive; };
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+
+struct SceneBuilder {
+    HostScene& hs;
+    std::string path;
+    std::map<std::string, V3> textures;               // scalar-valued (constant-folded)
+    std::map<std::string, uint32_t> materials, surfaces, mediums;
+    std::map<std::string, PrimRec> prims;
+    std::vector<V3> avg_emissive;                     // per surface
+    struct InstRec { spt_instance inst; Affine trans; std::string name; };
+    std::map<std::string, InstRec> instances;         // name-sorted (Q7: reference order is HashMap order)
+    std::map<std::string, spt_light> lights;
+    bool has_env = false;
+    std::vector<ObjMesh> mesh_src;                    // per mesh, leaf order (for area / power)
+
+    explicit SceneBuilder(HostScene& h, std::string p) : hs(h), path(std::move(p)) {}
+
+    using LoadFn = void (SceneBuilder::*)(Params&);
+
+    // load_from_value_or_external (src/loader/json.rs:212-242)
+    void load_section(const JsonValue& v, const char* env, LoadFn fn, bool allow_array) {
+        if (v.kind == JsonValue::String) {
+            std::string ext = with_file_name(path, v.s);
+            JsonValue sub;
+            try {
+                sub = parse_json_file(ext);
+            } catch (const HostError& e) {
+                if (e.code == SPT_HOST_ERR_IO) throw HostError(SPT_HOST_ERR_IO, std::string(env) + " - External json file not found: " + ext);
+                throw;
+            }
+            load_section(sub, env, fn, allow_array);
+        } else if (v.kind == JsonValue::Array) {
+            if (!allow_array) throw HostError(SPT_HOST_ERR_SCHEMA, std::string(env) + " - Field should not be an array");
+            for (auto& e : v.arr) load_section(e, env, fn, true);
+        } else {
+            Params p(v, path);
+            (this->*fn)(p);
+        }
+    }
+
+    V3 texture(const std::string& name) {
+        auto it = textures.find(name);
+        if (it == textures.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no texture named '" + name + "'");
+        return it->second;
+    }
+
+    // camera::create_camera_from_params + PerspectiveCamera::new (src/camera/perspective.rs:15-37)
+    void load_camera(Params& p) {
+        p.set_name("camera");
+        std::string ty = p.get_str("type"), name = p.get_str("name");
+        p.set_name("camera-" + ty + "-" + name);
+        if (ty != "perspective") throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        V3 eye = p.get_float3("eye"), fwd = p.get_float3("forward"), up = p.get_float3("up");
+        float fov = p.get_float("fov") * 3.14159265358979323846f / 180.0f;
+        if (hs.camera_index.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated camera name '" + name + "'");
+        spt_camera c;
+        V3 f = normalize(fwd);
+        V3 r = normalize(cross(f, up));
+        V3 u = cross(r, f);
+        c.eye[0] = eye.x; c.eye[1] = eye.y; c.eye[2] = eye.z;
+        c.forward[0] = f.x; c.forward[1] = f.y; c.forward[2] = f.z;
+        c.up[0] = u.x; c.up[1] = u.y; c.up[2] = u.z;
+        c.right[0] = r.x; c.right[1] = r.y; c.right[2] = r.z;
+        c.half_cot_half_fov = 0.5f / std::tan(fov * 0.5f);
+        hs.camera_index[name] = hs.cameras.size();
+        hs.cameras.push_back(c);
+        p.check_unused();
+    }
+
+    // texture::create_texture_from_params (src/texture/mod.rs:210-243), scalar-valued subset
+    void load_texture(Params& p) {
+        p.set_name("texture");
+        std::string ty = p.get_str("type"), name = p.get_str("name");
+        p.set_name("texture-" + ty + "-" + name);
+        V3 val;
+        if (ty == "scalar") {
+            val = p.get_float3("value");
+        } else if (ty == "add" || ty == "sub" || ty == "mul" || ty == "div") {
+            V3 a = texture(p.get_str("t1")), b = texture(p.get_str("t2"));
+            if (ty == "add") val = a + b;
+            else if (ty == "sub") val = a - b;
+            else if (ty == "mul") val = a * b;
+            else val = {a.x / b.x, a.y / b.y, a.z / b.z};
+        } else if (ty == "image") {
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": image textures are outside the hot-path scope (SURVEY 8f-2)");
+        } else {
+            throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        }
+        if (p.get_bool_or("is_srgb", false)) val = {srgb_to_linear(val.x), srgb_to_linear(val.y), srgb_to_linear(val.z)};
+        // remaining keys (tiling/offset/mode/wrap) wrap the texture in a TexInputModifier,
+        // which is the identity for a constant texture
+        for (const char* k : {"tiling", "offset", "mode", "wrap"})
+            if (p.contains(k)) p.mark(k);
+        if (textures.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated texture name '" + name + "'");
+        textures[name] = val;
+        p.check_unused();
+    }
+
+    // material::create_material_from_params + MaterialT::bxdf_context for scalar textures
+    void load_material(Params& p) {
+        p.set_name("material");
+        std::string ty = p.get_str("type"), name = p.get_str("name");
+        p.set_name("material-" + ty + "-" + name);
+        spt_material m;
+        std::memset(&m, 0, sizeof m);
+        auto roughness = [&](float& ax, float& ay) {
+            float rx, ry;
+            if (p.contains("roughness")) {
+                rx = ry = texture(p.get_str("roughness")).x;
+            } else {
+                rx = texture(p.get_str("roughness_x")).x;
+                ry = texture(p.get_str("roughness_y")).x;
+            }
+            ax = rx * rx;  // powi(2)
+            ay = ry * ry;
+        };
+        if (ty == "lambert") {
+            V3 a = texture(p.get_str("albedo"));
+            m.bxdf = SPT_BXDF_LAMBERT;
+            m.c0[0] = a.x; m.c0[1] = a.y; m.c0[2] = a.z;
+        } else if (ty == "conductor") {
+            V3 ior = texture(p.get_str("ior")), k = texture(p.get_str("ior_k"));
+            roughness(m.ax, m.ay);
+            m.bxdf = (m.ax < 0.0001f || m.ay < 0.0001f) ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
+            m.c0[0] = ior.x; m.c0[1] = ior.y; m.c0[2] = ior.z;
+            m.c1[0] = k.x; m.c1[1] = k.y; m.c1[2] = k.z;
+        } else if (ty == "dielectric") {
+            float int_ior = p.get_float("int_ior");
+            float ext_ior = p.get_float_or("ext_ior", 1.0f);
+            (void)texture(p.get_str("reflectance"));    // loaded, never used (dielectric.rs:67-68)
+            (void)texture(p.get_str("transmittance"));
+            roughness(m.ax, m.ay);
+            m.ior = int_ior / ext_ior;
+            m.bxdf = (m.ax < 0.0001f || m.ay < 0.0001f) ? SPT_BXDF_SPECULAR_DIELECTRIC : SPT_BXDF_MICROFACET_DIELECTRIC;
+        } else if (ty == "pseudo") {
+            m.bxdf = SPT_BXDF_PSEUDO;
+        } else if (ty == "plastic" || ty == "pbr_metallic" || ty == "pbr_specular" || ty == "pndf_conductor" ||
+                   ty == "pndf_plastic" || ty == "subsurface") {
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)");
+        } else {
+            throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        }
+        if (materials.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated material name '" + name + "'");
+        materials[name] = (uint32_t)hs.materials.size();
+        hs.materials.push_back(m);
+        p.check_unused();
+    }
+
+    // medium::create_medium_from_params + Homogeneous::load (src/medium/homogeneous.rs:21-27):
+    // sigma_s is read from the key "sigma_a" (reference quirk Q4, replicated).
+    void load_medium(Params& p) {
+        p.set_name("medium");
+        std::string ty = p.get_str("type"), name = p.get_str("name");
+        p.set_name("medium-" + ty + "-" + name);
+        if (ty != "homogeneous") throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        V3 sa = p.get_float3("sigma_a");
+        V3 ss = p.get_float3("sigma_a");
+        float g = p.get_float("asymmetric");
+        spt_medium m;
+        std::memset(&m, 0, sizeof m);
+        V3 st = sa + ss;
+        m.sigma_t[0] = st.x; m.sigma_t[1] = st.y; m.sigma_t[2] = st.z;
+        m.sigma_s[0] = ss.x; m.sigma_s[1] = ss.y; m.sigma_s[2] = ss.z;
+        m.g = g;
+        if (mediums.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated medium name '" + name + "'");
+        mediums[name] = (uint32_t)hs.mediums.size();
+        hs.mediums.push_back(m);
+        p.check_unused();
+    }
+
+    // primitive::create_primitive_from_params (src/primitive/mod.rs:55-77)
+    void load_primitive(Params& p) {
+        p.set_name("primitive");
+        std::string ty = p.get_str("type"), name = p.get_str("name");
+        p.set_name("primitive-" + ty + "-" + name);
+        PrimRec rec;
+        if (ty == "sphere") {
+            V3 c = p.get_float3_or("center", {0, 0, 0});
+            float r = p.get_float("radius");
+            spt_sphere s = {{c.x, c.y, c.z}, r};
+            rec.type = SPT_PRIM_SPHERE;
+            rec.id = (uint32_t)hs.spheres.size();
+            rec.box.lo = c - V3{r, r, r};
+            rec.box.hi = c + V3{r, r, r};
+            hs.spheres.push_back(s);
+        } else if (ty == "trimesh") {
+            ObjMesh m = load_obj(p.get_file_path("obj_file"));
+            calc_tangents(m);
+            rec.type = SPT_PRIM_MESH;
+            rec.id = add_mesh(m, rec.box);
+        } else if (ty == "cubic_bezier" || ty == "catmull_clark") {
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": primitive type '" + ty + "' is outside the hot-path scope (SURVEY 2 #4)");
+        } else {
+            throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        }
+        if (prims.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated primitive name '" + name + "'");
+        prims[name] = rec;
+        p.check_unused();
+    }
+
+    // TriMesh::new (src/primitive/triangle.rs:42-55): triangles -> BLAS(4, 16), leaf order
+    uint32_t add_mesh(const ObjMesh& m, Box& root_box) {
+        uint32_t ntri = (uint32_t)(m.idx.size() / 3);
+        if (ntri == 0) throw HostError(SPT_HOST_ERR_SCHEMA, "trimesh without triangles");
+        std::vector<Box> boxes(ntri);
+        for (uint32_t t = 0; t < ntri; ++t)
+            for (int k = 0; k < 3; ++k) boxes[t].grow(m.pos[m.idx[3 * t + k]]);
+        BvhBuildResult bvh = BvhBuilder(boxes, 4, 16).build();
+        spt_mesh mesh;
+        mesh.root = (uint32_t)hs.blas_nodes.size();
+        mesh.node_count = (uint32_t)bvh.nodes.size();
+        mesh.tri_first = (uint32_t)hs.tri_pos.size();
+        mesh.tri_count = ntri;
+        for (auto nd : bvh.nodes) {
+            if (nd.b & SPT_LEAF_FLAG) nd.a += mesh.tri_first;
+            else { nd.a += mesh.root; nd.b += mesh.root; }
+            hs.blas_nodes.push_back(nd);
+        }
+        for (uint32_t k = 0; k < ntri; ++k) {
+            uint32_t t = bvh.order[k];
+            spt_tri_pos tp;
+            spt_tri_attr ta;
+            std::memset(&tp, 0, sizeof tp);
+            std::memset(&ta, 0, sizeof ta);
+            float* pp[3] = {tp.p0, tp.p1, tp.p2};
+            for (int c = 0; c < 3; ++c) {
+                uint32_t vi = m.idx[3 * t + c];
+                pp[c][0] = m.pos[vi].x; pp[c][1] = m.pos[vi].y; pp[c][2] = m.pos[vi].z;
+                ta.n[c][0] = m.nrm[vi].x; ta.n[c][1] = m.nrm[vi].y; ta.n[c][2] = m.nrm[vi].z;
+                ta.t[c][0] = m.tan[vi].x; ta.t[c][1] = m.tan[vi].y; ta.t[c][2] = m.tan[vi].z;
+                ta.b[c][0] = m.bit[vi].x; ta.b[c][1] = m.bit[vi].y; ta.b[c][2] = m.bit[vi].z;
+                ta.uv[c][0] = m.uv[2 * vi]; ta.uv[c][1] = m.uv[2 * vi + 1];
+            }
+            hs.tri_pos.push_back(tp);
+            hs.tri_attr.push_back(ta);
+        }
+        const spt_bvh_node& r = hs.blas_nodes[mesh.root];
+        root_box.lo = {r.bmin[0], r.bmin[1], r.bmin[2]};
+        root_box.hi = {r.bmax[0], r.bmax[1], r.bmax[2]};
+        hs.meshes.push_back(mesh);
+        return (uint32_t)hs.meshes.size() - 1;
+    }
+
+    uint32_t add_surface(uint32_t material, V3 emissive, bool double_sided, int32_t medium) {
+        spt_surface s;
+        std::memset(&s, 0, sizeof s);
+        s.material = material;
+        s.flags = double_sided ? (uint32_t)SPT_SURF_DOUBLE_SIDED : 0u;
+        s.inside_medium = medium;
+        s.emissive[0] = emissive.x; s.emissive[1] = emissive.y; s.emissive[2] = emissive.z;
+        hs.surfaces.push_back(s);
+        avg_emissive.push_back(emissive);
+        return (uint32_t)hs.surfaces.size() - 1;
+    }
+
+    // Surface::load (src/core/surface.rs:117-164)
+    void load_surface(Params& p) {
+        p.set_name("surface");
+        std::string name = p.get_str("name");
+        p.set_name("surface-" + name);
+        std::string mat = p.get_str("material");
+        auto mi = materials.find(mat);
+        if (mi == materials.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no material named '" + mat + "'");
+        for (const char* k : {"normal_map", "emissive_map"})
+            if (p.contains(k)) {
+                (void)texture(p.get_str(k));
+                throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": '" + k + "' is outside the hot-path scope (SURVEY 8f-2)");
+            }
+        if (p.contains("displacement_map")) (void)texture(p.get_str("displacement_map"));  // loaded, unused (surface.rs:17)
+        V3 em = p.get_float3_or("emissive", {0, 0, 0});
+        bool ds = p.get_bool_or("double_sided", false);
+        int32_t med = -1;
+        if (p.contains("inside_medium")) {
+            std::string mn = p.get_str("inside_medium");
+            auto it = mediums.find(mn);
+            if (it == mediums.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no medium named '" + mn + "'");
+            med = (int32_t)it->second;
+        }
+        if (surfaces.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated surface name '" + name + "'");
+        surfaces[name] = add_surface(mi->second, em, ds, med);
+        p.check_unused();
+    }
+
+    // Instance::load + Instance::new (src/primitive/instance.rs:19-85)
+    void load_instance(Params& p) {
+        p.set_name("instance");
+        std::string name = p.get_str("name");
+        p.set_name("instance-" + name);
+        const float deg = 3.14159265358979323846f / 180.0f;
+        Affine trans;
+        if (p.contains("matrix")) trans = p.get_matrix("matrix");
+        if (p.contains("scale")) trans = from_scale(p.get_float3("scale")) * trans;
+        if (p.contains("rotate")) {
+            V3 r = p.get_float3("rotate");
+            trans = from_rotation_z(r.z * deg) * from_rotation_x(r.x * deg) * from_rotation_y(r.y * deg) * trans;
+        }
+        if (p.contains("translate")) trans = from_translation(p.get_float3("translate")) * trans;
+        if (determinant(trans.m) == 0.0f) warn(p.name() + ": transform matrix is singular");
+        uint32_t surf;
+        if (p.contains("surface")) {
+            std::string sn = p.get_str("surface");
+            auto it = surfaces.find(sn);
+            if (it == surfaces.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no surface named '" + sn + "'");
+            surf = it->second;
+        } else {
+            std::string mn = p.get_str("material");
+            auto it = materials.find(mn);
+            if (it == materials.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no material named '" + mn + "'");
+            surf = add_surface(it->second, {0, 0, 0}, false, -1);
+        }
+        std::string pn = p.get_str("primitive");
+        auto pi = prims.find(pn);
+        if (pi == prims.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no primitive named '" + pn + "'");
+
+        InstRec rec;
+        rec.name = name;
+        rec.trans = trans;
+        spt_instance& in = rec.inst;
+        std::memset(&in, 0, sizeof in);
+        Affine inv = inverse(trans);
+        M3 it3 = transpose(inv.m);  // Transform::new: trans_it = inverse.matrix3.transpose()
+        auto put = [](float* dst, const Affine& a) {
+            const V3 cols[4] = {a.m.c0, a.m.c1, a.m.c2, a.t};
+            for (int c = 0; c < 4; ++c) { dst[3 * c] = cols[c].x; dst[3 * c + 1] = cols[c].y; dst[3 * c + 2] = cols[c].z; }
+        };
+        put(in.inv, inv);
+        put(in.fwd, trans);
+        const V3 nc[3] = {it3.c0, it3.c1, it3.c2};
+        for (int c = 0; c < 3; ++c) { in.nrm[3 * c] = nc[c].x; in.nrm[3 * c + 1] = nc[c].y; in.nrm[3 * c + 2] = nc[c].z; }
+        in.prim_type = pi->second.type;
+        in.prim_id = pi->second.id;
+        in.surface = surf;
+        in.light = -1;
+        // Bbox::transformed_by (src/core/bbox.rs:40-61): the 8 corners
+        const Box& pb = pi->second.box;
+        Box wb;
+        for (int c = 0; c < 8; ++c)
+            wb.grow(trans.point({(c & 4) ? pb.hi.x : pb.lo.x, (c & 2) ? pb.hi.y : pb.lo.y, (c & 1) ? pb.hi.z : pb.lo.z}));
+        in.bmin[0] = wb.lo.x; in.bmin[1] = wb.lo.y; in.bmin[2] = wb.lo.z;
+        in.bmax[0] = wb.hi.x; in.bmax[1] = wb.hi.y; in.bmax[2] = wb.hi.z;
+        if (instances.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated instance name '" + name + "'");
+        instances[name] = rec;
+        p.check_unused();
+    }
+
+    // light::create_light_from_params (src/light/mod.rs:37-59)
+    void load_light(Params& p) {
+        p.set_name("light");
+        std::string ty = p.get_str("type"), name = p.get_str("name");
+        p.set_name("light-" + ty + "-" + name);
+        spt_light l;
+        std::memset(&l, 0, sizeof l);
+        auto set3 = [](float* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+        if (ty == "directional") {
+            l.type = SPT_LIGHT_DIRECTIONAL;
+            V3 d = p.get_float3("direction"), s = p.get_float3("strength");
+            set3(l.dir, normalize(d));  // DirLight::new normalises
+            set3(l.strength, s);
+        } else if (ty == "point") {
+            l.type = SPT_LIGHT_POINT;
+            set3(l.pos, p.get_float3("position"));
+            set3(l.strength, p.get_float3("strength"));
+        } else if (ty == "spot") {
+            l.type = SPT_LIGHT_SPOT;
+            const float deg = 3.14159265358979323846f / 180.0f;
+            set3(l.pos, p.get_float3("position"));
+            set3(l.dir, p.get_float3("direction"));  // NOT normalised (spot.rs:18-31)
+            float inner = p.get_float_or("inner_angle", 0.0f) * deg;
+            float outer = p.get_float_or("outer_angle", 90.0f) * deg;
+            l.cos_inner = std::cos(inner);
+            l.cos_outer = std::cos(outer);
+            set3(l.strength, p.get_float3("strength"));
+        } else {
+            throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        }
+        l.power = luminance({l.strength[0], l.strength[1], l.strength[2]});
+        if (lights.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated light name '" + name + "'");
+        lights[name] = l;
+        p.check_unused();
+    }
+
+    // EnvLight::load / ::new (src/light/environment.rs:19-49, 86-107)
+    void load_env(Params& p) {
+        p.set_name("environment");
+        std::string ty = p.get_str("type");
+        V3 scale = p.get_float3_or("scale", {1, 1, 1});
+        uint32_t w = 0, h = 0;
+        std::vector<float> tex;
+        if (ty == "color") {
+            V3 c = p.get_float3("color");
+            w = h = 1;
+            tex = {c.x, c.y, c.z};
+        } else if (ty == "exr") {
+            std::string file = p.get_file_path("exr_file");
+            float* data = nullptr;
+            spt_status st = spt_host_read_exr(file.c_str(), &w, &h, &data);
+            if (st != SPT_OK) throw HostError(st, spt_host_last_error());
+            tex.assign(data, data + (size_t)w * h * 3);
+            spt_host_free(data);
+        } else {
+            throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + " - unknown type");
+        }
+        if (has_env) throw HostError(SPT_HOST_ERR_SCHEMA, "Environment has been set before");
+        has_env = true;
+        size_t n = (size_t)w * h;
+        hs.env_texels = tex;
+        hs.env_props.resize(n);
+        float sum = 0.0f;
+        float height_inv = 1.0f / (float)h;
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = 0; x < w; ++x) {
+                const float* px = &tex[3 * ((size_t)y * w + x)];
+                float theta = ((float)y + 0.5f) * height_inv;  // NOT scaled by pi (quirk Q5)
+                float prop = luminance({px[0], px[1], px[2]}) * std::sin(theta);
+                sum += prop;
+                hs.env_props[(size_t)y * w + x] = prop;
+            }
+        float sum_inv = 1.0f / sum;
+        for (auto& pr : hs.env_props) pr *= sum_inv;
+        float avg_power = sum / (float)n;
+        build_alias(hs.env_props, hs.env_u, hs.env_k);
+        hs.env_w = w; hs.env_h = h;
+        hs.env_scale[0] = scale.x; hs.env_scale[1] = scale.y; hs.env_scale[2] = scale.z;
+        spt_light l;
+        std::memset(&l, 0, sizeof l);
+        l.type = SPT_LIGHT_ENV;
+        l.power = avg_power * 4.0f * 3.14159265358979323846f;
+        lights["$env"] = l;  // add_environment registers it as light "$env" (scene_resources.rs:158-168)
+        p.check_unused();
+    }
+
+    // AliasTable::new (src/core/alias_table.rs:7-58), same pairing order
+    static void build_alias(const std::vector<float>& props, std::vector<float>& u, std::vector<uint32_t>& k) {
+        size_t n = props.size();
+        u.resize(n);
+        k.resize(n);
+        for (size_t i = 0; i < n; ++i) { u[i] = props[i] * (float)n; k[i] = (uint32_t)i; }
+        const size_t NONE = (size_t)-1;
+        size_t poor = NONE, rich = NONE;
+        for (size_t i = 0; i < n; ++i) if (u[i] < 1.0f) { poor = i; break; }
+        size_t poor_max = poor;
+        for (size_t i = 0; i < n; ++i) if (u[i] > 1.0f) { rich = i; break; }
+        while (poor != NONE && rich != NONE) {
+            float diff = 1.0f - u[poor];
+            u[rich] -= diff;
+            k[poor] = (uint32_t)rich;
+            if (u[rich] < 1.0f && rich < poor_max) {
+                poor = rich;
+            } else {
+                poor = NONE;
+                for (size_t i = poor_max + 1; i < n; ++i)
+                    if (u[i] < 1.0f) { poor = i; poor_max = i; break; }
+            }
+            size_t start = rich;
+            rich = NONE;
+            for (size_t i = start; i < n; ++i)
+                if (u[i] > 1.0f) { rich = i; break; }
+        }
+    }
+
+    // PrimitiveT::surface_area for an instance under `trans` (Instance/TriMesh/Sphere ::surface_area)
+    float instance_area(const InstRec& r) {
+        const spt_instance& in = r.inst;
+        if (in.prim_type == SPT_PRIM_SPHERE) {
+            float rad = hs.spheres[in.prim_id].radius * 0.5f;
+            V3 v0 = r.trans.vector({-rad, -rad, -rad}), v1 = r.trans.vector({-rad, -rad, rad});
+            V3 v2 = r.trans.vector({-rad, rad, -rad}), v3 = r.trans.vector({rad, -rad, -rad});
+            auto d2 = [](V3 a, V3 b) { V3 d = a - b; return dot(d, d); };
+            float a2 = d2(v0, v1), b2 = d2(v0, v2), c2 = d2(v0, v3);
+            return 4.0f * 3.14159265358979323846f * std::sqrt((a2 * b2 + b2 * c2 + c2 * a2) / 3.0f);
+        }
+        const spt_mesh& m = hs.meshes[in.prim_id];
+        float sum = 0.0f;
+        for (uint32_t t = m.tri_first; t < m.tri_first + m.tri_count; ++t) {
+            const spt_tri_pos& tp = hs.tri_pos[t];
+            V3 p0 = r.trans.point({tp.p0[0], tp.p0[1], tp.p0[2]});
+            V3 p1 = r.trans.point({tp.p1[0], tp.p1[1], tp.p1[2]});
+            V3 p2 = r.trans.point({tp.p2[0], tp.p2[1], tp.p2[2]});
+            sum += length(cross(p1 - p0, p2 - p0)) * 0.5f;
+        }
+        return sum;
+    }
+
+    void finish(const JsonValue& root) {
+        // aggregate: "group" | "bvh" (default bvh(4,16))  (scene_resources.rs:85-103)
+        uint32_t aggregate = SPT_AGGREGATE_BVH;
+        if (const JsonValue* a = root.get("aggregate")) {
+            if (a->kind != JsonValue::String) throw HostError(SPT_HOST_ERR_SCHEMA, "scene - 'aggregate' should be string");
+            if (a->s == "group") aggregate = SPT_AGGREGATE_GROUP;
+            else if (a->s == "bvh") aggregate = SPT_AGGREGATE_BVH;
+            else throw HostError(SPT_HOST_ERR_SCHEMA, "Unknown aggregate type '" + a->s + "'");
+        }
+        uint32_t sampler = SPT_LIGHT_SAMPLER_UNIFORM;
+        if (const JsonValue* a = root.get("light_sampler")) {
+            if (a->kind != JsonValue::String) throw HostError(SPT_HOST_ERR_SCHEMA, "scene - 'light_sampler' should be string");
+            if (a->s == "uniform") sampler = SPT_LIGHT_SAMPLER_UNIFORM;
+            else if (a->s == "power_is") sampler = SPT_LIGHT_SAMPLER_POWER_IS;
+            else throw HostError(SPT_HOST_ERR_SCHEMA, "Unknown light sampler type '" + a->s + "'");
+        }
+        if (hs.cameras.empty()) throw HostError(SPT_HOST_ERR_SCHEMA, "At least one camera is needed");
+
+        // instances in name order, then TLAS
+        std::vector<const InstRec*> recs;
+        for (auto& kv : instances) recs.push_back(&kv.second);
+        std::vector<Box> boxes(recs.size());
+        for (size_t i = 0; i < recs.size(); ++i) {
+            const spt_instance& in = recs[i]->inst;
+            boxes[i].lo = {in.bmin[0], in.bmin[1], in.bmin[2]};
+            boxes[i].hi = {in.bmax[0], in.bmax[1], in.bmax[2]};
+        }
+        std::vector<const InstRec*> ordered;
+        if (aggregate == SPT_AGGREGATE_GROUP || recs.empty()) {
+            spt_bvh_node root_node;
+            std::memset(&root_node, 0, sizeof root_node);
+            Box all;
+            for (auto& b : boxes) all.grow(b);
+            root_node.bmin[0] = all.lo.x; root_node.bmin[1] = all.lo.y; root_node.bmin[2] = all.lo.z;
+            root_node.bmax[0] = all.hi.x; root_node.bmax[1] = all.hi.y; root_node.bmax[2] = all.hi.z;
+            root_node.a = 0;
+            root_node.b = SPT_LEAF_FLAG | (uint32_t)recs.size();
+            hs.tlas_nodes.push_back(root_node);
+            ordered = recs;
+        } else {
+            BvhBuildResult bvh = BvhBuilder(boxes, 4, 16).build();
+            hs.tlas_nodes = bvh.nodes;
+            for (uint32_t k : bvh.order) ordered.push_back(recs[k]);
+        }
+        std::map<std::string, uint32_t> inst_index;
+        for (auto* r : ordered) {
+            inst_index[r->name] = (uint32_t)hs.instances.size();
+            hs.instances.push_back(r->inst);
+        }
+
+        // lights: named lights (incl. "$env") in name order, then one ShapeLight per emissive
+        // instance in name order (scene_resources.rs:105-122)
+        int32_t env_index = -1;
+        for (auto& kv : lights) {
+            if (kv.second.type == SPT_LIGHT_ENV) env_index = (int32_t)hs.lights.size();
+            hs.lights.push_back(kv.second);
+        }
+        for (auto& kv : instances) {
+            const InstRec& r = kv.second;
+            V3 em = avg_emissive[r.inst.surface];
+            if (luminance(em) > 0.0f) {  // Surface::is_emissive
+                spt_light l;
+                std::memset(&l, 0, sizeof l);
+                l.type = SPT_LIGHT_SHAPE;
+                l.instance = inst_index[r.name];
+                l.power = instance_area(r) * luminance(em);
+                hs.instances[l.instance].light = (int32_t)hs.lights.size();
+                hs.lights.push_back(l);
+            }
+        }
+        hs.aggregate = aggregate;
+        hs.light_sampler = sampler;
+        hs.env_light_index = env_index;
+        if (sampler == SPT_LIGHT_SAMPLER_POWER_IS) {
+            // PowerIsLightSampler::new (src/light_sampler/power_is.rs:24-46)
+            size_t n = hs.lights.size();
+            hs.light_props.assign(n, 0.0f);
+            float sum = 0.0f;
+            for (size_t i = 0; i < n; ++i) { hs.light_props[i] = hs.lights[i].power; sum += hs.light_props[i]; }
+            float sum_inv = 1.0f / sum;
+            for (auto& pr : hs.light_props) pr *= sum_inv;
+            build_alias(hs.light_props, hs.light_u, hs.light_k);
+        }
+        hs.finalize_desc();
+    }
+};
+
+void HostScene::finalize_desc() {
+    std::memset(&desc, 0, sizeof desc);
+    desc.abi_version = SPT_ABI_VERSION;
+    desc.aggregate = aggregate;
+    desc.n_tlas_nodes = (uint32_t)tlas_nodes.size(); desc.tlas_nodes = tlas_nodes.data();
+    desc.n_instances = (uint32_t)instances.size(); desc.instances = instances.data();
+    desc.n_meshes = (uint32_t)meshes.size(); desc.meshes = meshes.data();
+    desc.n_blas_nodes = (uint32_t)blas_nodes.size(); desc.blas_nodes = blas_nodes.data();
+    desc.n_tris = (uint32_t)tri_pos.size(); desc.tri_pos = tri_pos.data(); desc.tri_attr = tri_attr.data();
+    desc.n_spheres = (uint32_t)spheres.size(); desc.spheres = spheres.data();
+    desc.n_surfaces = (uint32_t)surfaces.size(); desc.surfaces = surfaces.data();
+    desc.n_materials = (uint32_t)materials.size(); desc.materials = materials.data();
+    desc.n_mediums = (uint32_t)mediums.size(); desc.mediums = mediums.data();
+    desc.n_lights = (uint32_t)lights.size(); desc.lights = lights.data();
+    desc.light_sampler = light_sampler;
+    desc.env_light_index = env_light_index;
+    desc.light_alias.n = (uint32_t)light_props.size();
+    desc.light_alias.props = light_props.data();
+    desc.light_alias.u = light_u.data();
+    desc.light_alias.k = light_k.data();
+    desc.env.width = env_w; desc.env.height = env_h;
+    desc.env.texels = env_texels.data();
+    for (int i = 0; i < 3; ++i) desc.env.scale[i] = env_scale[i];
+    desc.env.alias.n = (uint32_t)env_props.size();
+    desc.env.alias.props = env_props.data();
+    desc.env.alias.u = env_u.data();
+    desc.env.alias.k = env_k.data();
+}
+
+// loader::load_scene (src/loader/json.rs:53-199): fixed section order
+HostScene* load_scene_file(const std::string& path) {
+    if (path.size() < 5 || path.substr(path.size() - 5) != ".json")
+        throw HostError(SPT_HOST_ERR_SCHEMA, "File extension is not recognized (only .json scenes are in scope)");
+    JsonValue root = parse_json_file(path);
+    if (root.kind != JsonValue::Object) throw HostError(SPT_HOST_ERR_SCHEMA, "scene - top level must be an object");
+    std::unique_ptr<HostScene> hs(new HostScene());
+    SceneBuilder b(*hs, path);
+    struct Sec { const char* key; const char* env; SceneBuilder::LoadFn fn; };
+    const Sec secs[] = {
+        {"cameras", "json-cameras", &SceneBuilder::load_camera},
+        {"textures", "json-textures", &SceneBuilder::load_texture},
+        {"materials", "json-materials", &SceneBuilder::load_material},
+        {"mediums", "json-mediums", &SceneBuilder::load_medium},
+        {"primitives", "json-primitives", &SceneBuilder::load_primitive},
+        {"surfaces", "json-surfaces", &SceneBuilder::load_surface},
+        {"instances", "json-instances", &SceneBuilder::load_instance},
+        {"lights", "json-lights", &SceneBuilder::load_light},
+    };
+    for (auto& s : secs) {
+        const JsonValue* v = root.get(s.key);
+        if (!v) throw HostError(SPT_HOST_ERR_SCHEMA, std::string("scene - There is no '") + s.key + "' field");
+        b.load_section(*v, s.env, s.fn, true);
+    }
+    if (const JsonValue* v = root.get("environment")) b.load_section(*v, "json-environment", &SceneBuilder::load_env, false);
+    if (root.get("gltf")) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "scene - 'gltf' import is outside the hot-path scope (SURVEY 2 #20)");
+    b.finish(root);
+    return hs.release();
+}
+
+}  // namespace spt_host
