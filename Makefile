@@ -10,7 +10,7 @@ LIBDIR   := $(PKG)/lib
 CXX      ?= g++
 HIPCC    ?= hipcc
 CXXFLAGS := -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fno-fast-math -Iinclude
-HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fgpu-rdc=0 \
+HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
             -Wall -Wno-unused-function -Iinclude
 
 HOST_SRC := $(wildcard $(PKG)/csrc/host/*.cpp)

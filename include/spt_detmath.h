@@ -43,9 +43,17 @@ SPT_HD float spt_abs(float x) { return spt_u2f(spt_f2u(x) & 0x7fffffffu); }
 /* Rust f32::is_finite */
 SPT_HD bool spt_is_finite(float x) { return (spt_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
-/* Rust f32::max / f32::min: a NaN operand is ignored (IEEE maxNum/minNum). */
+/* Rust f32::max / f32::min: a NaN operand is ignored (IEEE maxNum/minNum).
+ * On gfx950 this is one v_max_f32 / v_min_f32.  The two sides may differ in the
+ * SIGN of a zero result (max(-0,+0)); no caller lets that sign reach a division
+ * or an output, only comparisons and sums, so results stay bit-identical. */
+#if defined(__HIP_DEVICE_COMPILE__)
+SPT_HD float spt_max(float a, float b) { return __builtin_fmaxf(a, b); }
+SPT_HD float spt_min(float a, float b) { return __builtin_fminf(a, b); }
+#else
 SPT_HD float spt_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
 SPT_HD float spt_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
+#endif
 
 /* Rust f32::clamp(lo, hi): NaN passes through. */
 SPT_HD float spt_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -245,13 +253,10 @@ SPT_HD float spt_acos(float x) {
     return 1.5707963267948966f - spt_asin(x);
 }
 
-/* correctly rounded sqrt on both sides (x86 sqrtss; gfx950 via
- * -fhip-fp32-correctly-rounded-divide-sqrt, the hipcc default) */
-#if defined(__HIP_DEVICE_COMPILE__)
-SPT_HD float spt_sqrt(float x) { return __fsqrt_rn(x); }
-#else
+/* correctly rounded sqrt on both sides: x86 sqrtss; gfx950 llvm.sqrt.f32 under hipcc's
+ * default -fhip-fp32-correctly-rounded-divide-sqrt.  (HIP's __fsqrt_rn is NOT usable: without
+ * OCML_BASIC_ROUNDED_OPERATIONS it is the approximate native sqrt.) */
 SPT_HD float spt_sqrt(float x) { return __builtin_sqrtf(x); }
-#endif
 
 /* ---- per-path random numbers --------------------------------------------------
  * Replaces SmallRng::from_entropy (src/core/rng.rs:8-12, one generator per

@@ -1,0 +1,1378 @@
+// oracle.cpp — CPU restatement of the reference's per-pixel radiance loop.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing in the product (libspt_hip.so, libspt_host.so,
+// the CLI, the python package) links, loads or calls this file; only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the checker.
+//
+// What it restates (reference = /root/reference, PepcyCh/simple-path-tracer, Rust):
+//   src/renderer/pt.rs            trace_ray, shadow_ray_from_medium, render, power_heuristic
+//   src/primitive/{bvh,group,instance,triangle,sphere}.rs   intersect / intersect_test / sample / pdf
+//   src/core/{ray,bbox,intersection,coord,transform,color,film}.rs
+//   src/core/surface.rs, src/material/*.rs (resolved on the host for scalar textures)
+//   src/bxdf/{lambert,util,fresnel,microfacet,microfacet_conductor,microfacet_dielectric,
+//             specular_conductor,specular_dielectric,pseudo}.rs
+//   src/light_sampler/{uniform,power_is}.rs, src/core/alias_table.rs, src/light/*.rs
+//   src/medium/{homogeneous,util}.rs, src/camera/perspective.rs, src/pixel_sampler/*.rs
+// Each function cites the lines it follows.  Scalar f32, one expression per
+// reference expression, same operation order (glam 0.20 conventions: dot =
+// (x*x'+y*y')+z*z', Mat3*v = (c0*x+c1*y)+c2*z, normalize = v/sqrt(dot)).
+//
+// PARITY STATUS: UNPINNED against the Rust reference itself.  The reference cannot
+// be built here (no cargo/rustc, un-vendored crates) and ships no tests, golden
+// images or fixtures for this path.  The oracle is pinned instead by
+// closed-form known answers for the two shipped scenes and by hand-derived unit
+// KATs (tests/test_oracle_*.py).
+//
+// Deliberate, documented differences from a literal transcription:
+//   D1  RNG: per-sample PCG32 keyed by (seed, pixel, sample) instead of a per-thread
+//       entropy-seeded Xoshiro (src/core/rng.rs:8-12); recurrence sampler in closed
+//       form (include/spt_detmath.h).
+//   D2  sin/cos/ln/exp/acos/atan2 come from include/spt_detmath.h so that the GPU can
+//       match bit-for-bit (ORACLE_LIBM switches to libm to measure the difference).
+//   D3  Film: running f32 sum per pixel instead of a Vec of samples (src/core/film.rs:47-51);
+//       identical result for the box filter of radius <= 0.5.
+//   D4  BVH: the flattened arrays of include/spt_abi.h built by the host loader, traversed
+//       in the reference's order (push left, push right, pop; src/primitive/bvh.rs:262-283).
+//       ORACLE_SLAB_RECIPROCAL evaluates the slab test with a precomputed 1/d (what the
+//       kernels do) instead of the reference's six divisions (src/core/bbox.rs:68-79);
+//       ORACLE_BRUTE_FORCE ignores every BVH and tests all primitives linearly.
+//   D5  Where the reference would panic (no light at all: src/light_sampler/uniform.rs:34-36;
+//       in-medium ray that leaves the scene: src/renderer/pt.rs:77 `unwrap`), the oracle
+//       skips the light sample / uses the light distance, as the kernels do.
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../include/spt_abi.h"
+#include "../include/spt_detmath.h"
+#include "oracle.h"
+
+namespace {
+
+// ---------------------------------------------------------------- math (glam order)
+struct Vec3 {
+    float x, y, z;
+};
+inline Vec3 v3(float x, float y, float z) { return Vec3{x, y, z}; }
+inline Vec3 v3(const float* p) { return Vec3{p[0], p[1], p[2]}; }
+inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 operator-(Vec3 a) { return {-a.x, -a.y, -a.z}; }
+inline Vec3 operator*(Vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline Vec3 operator*(float s, Vec3 a) { return {a.x * s, a.y * s, a.z * s}; }
+inline Vec3 operator/(Vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float length_squared(Vec3 a) { return dot(a, a); }
+inline float length(Vec3 a) { return spt_sqrt(dot(a, a)); }
+inline Vec3 normalize(Vec3 a) { return a / length(a); }
+
+// src/core/color.rs
+struct Color {
+    float r, g, b;
+};
+inline Color col(float r, float g, float b) { return Color{r, g, b}; }
+inline Color col(const float* p) { return Color{p[0], p[1], p[2]}; }
+inline Color gray(float v) { return Color{v, v, v}; }
+inline Color operator+(Color a, Color b) { return {a.r + b.r, a.g + b.g, a.b + b.b}; }
+inline Color operator-(Color a, Color b) { return {a.r - b.r, a.g - b.g, a.b - b.b}; }
+inline Color operator-(Color a) { return {-a.r, -a.g, -a.b}; }
+inline Color operator*(Color a, float s) { return {a.r * s, a.g * s, a.b * s}; }
+inline Color operator*(float s, Color a) { return a * s; }                                 // color.rs:123-129
+inline Color operator*(Color a, Color b) { return {a.r * b.r, a.g * b.g, a.b * b.b}; }
+inline Color operator/(Color a, float s) { return a * (1.0f / s); }                         // color.rs:145-151
+inline Color operator/(Color a, Color b) { return {a.r / b.r, a.g / b.g, a.b / b.b}; }
+inline float luminance(Color c) { return 0.299f * c.r + 0.587f * c.g + 0.114f * c.b; }      // color.rs:30-32
+inline float avg(Color c) { return (c.r + c.g + c.b) / 3.0f; }
+inline bool is_finite(Color c) { return spt_is_finite(c.r) && spt_is_finite(c.g) && spt_is_finite(c.b); }
+
+struct Flags {
+    bool slab_recip, brute, libm;
+};
+
+struct Math {  // D2: deterministic kernels by default, libm on request
+    bool libm;
+    void sincos(float x, float* s, float* c) const {
+        if (libm) { *s = std::sin(x); *c = std::cos(x); } else spt_sincos(x, s, c);
+    }
+    float sin(float x) const { return libm ? std::sin(x) : spt_sin(x); }
+    float cos(float x) const { return libm ? std::cos(x) : spt_cos(x); }
+    float ln(float x) const { return libm ? std::log(x) : spt_log(x); }
+    float exp(float x) const { return libm ? std::exp(x) : spt_exp(x); }
+    float acos(float x) const { return libm ? std::acos(x) : spt_acos(x); }
+    float atan2(float y, float x) const { return libm ? std::atan2(y, x) : spt_atan2(y, x); }
+    Color exp(Color c) const { return col(exp(c.r), exp(c.g), exp(c.b)); }
+};
+
+// src/core/rng.rs:14-20
+struct Rng {
+    spt_rng s;
+    float uniform_1d() { return spt_rng_f32(&s); }
+    void uniform_2d(float* a, float* b) { *a = uniform_1d(); *b = uniform_1d(); }
+};
+
+// src/core/ray.rs:2-27 (aux rays are only consumed by image textures: not carried)
+struct Ray {
+    Vec3 origin, direction;
+    float t_min;
+};
+constexpr float T_MIN_EPS = 0.0001f;
+inline Ray make_ray(Vec3 o, Vec3 d) { return Ray{o, d, T_MIN_EPS}; }
+inline Vec3 point_at(const Ray& r, float t) { return r.origin + r.direction * t; }
+
+// glam Affine3A stored as 3 columns + translation (spt_instance::inv / fwd)
+inline Vec3 xf_vector(const float* m, Vec3 v) {
+    return (v3(m) * v.x + v3(m + 3) * v.y) + v3(m + 6) * v.z;
+}
+inline Vec3 xf_point(const float* m, Vec3 p) { return xf_vector(m, p) + v3(m + 9); }
+inline Vec3 mat3_mul(const float* m, Vec3 v) { return (v3(m) * v.x + v3(m + 3) * v.y) + v3(m + 6) * v.z; }
+
+// src/core/intersection.rs:6-18 (+ the ids the flattened scene needs)
+struct Inter {
+    float t = SPT_F32_MAX;
+    Vec3 position{0, 0, 0}, tangent{1, 0, 0}, bitangent{0, 1, 0}, normal{0, 0, 1};
+    int32_t instance = -1;   // Option<&Instance>
+    int32_t prim = -1;       // BasicPrimitiveRef: triangle (absolute) or sphere index
+    int32_t prim_type = -1;  // SPT_PRIM_*
+    float bv = 0, bw = 0;    // barycentrics of the accepted triangle hit
+};
+
+struct Counters {
+    uint64_t closest = 0, shadow = 0, nodes = 0, tris = 0, spheres = 0, insts = 0;
+};
+
+struct Ctx {
+    const spt_scene_desc* d;
+    Flags f;
+    Math m;
+    Counters* c;
+};
+
+// ---------------------------------------------------------------- src/core/bbox.rs:63-93
+inline bool bbox_intersect_test(const Ctx& cx, const spt_bvh_node& n, const Ray& ray, Vec3 inv_d, float t_max) {
+    cx.c->nodes++;
+    if (n.bmin[0] > n.bmax[0] || n.bmin[1] > n.bmax[1] || n.bmin[2] > n.bmax[2]) return false;  // is_empty
+    float x0, x1, y0, y1, z0, z1;
+    if (cx.f.slab_recip) {
+        x0 = (n.bmin[0] - ray.origin.x) * inv_d.x; x1 = (n.bmax[0] - ray.origin.x) * inv_d.x;
+        y0 = (n.bmin[1] - ray.origin.y) * inv_d.y; y1 = (n.bmax[1] - ray.origin.y) * inv_d.y;
+        z0 = (n.bmin[2] - ray.origin.z) * inv_d.z; z1 = (n.bmax[2] - ray.origin.z) * inv_d.z;
+    } else {
+        x0 = (n.bmin[0] - ray.origin.x) / ray.direction.x; x1 = (n.bmax[0] - ray.origin.x) / ray.direction.x;
+        y0 = (n.bmin[1] - ray.origin.y) / ray.direction.y; y1 = (n.bmax[1] - ray.origin.y) / ray.direction.y;
+        z0 = (n.bmin[2] - ray.origin.z) / ray.direction.z; z1 = (n.bmax[2] - ray.origin.z) / ray.direction.z;
+    }
+    float xa = spt_min(x0, x1), xb = spt_max(x0, x1);
+    float ya = spt_min(y0, y1), yb = spt_max(y0, y1);
+    float za = spt_min(z0, z1), zb = spt_max(z0, z1);
+    float t0 = spt_max(xa, spt_max(ya, za));
+    float t1 = spt_min(xb, spt_min(yb, zb));
+    if (!(t0 <= t1)) return false;
+    return t1 > ray.t_min && t0 < t_max;
+}
+inline Vec3 recip_dir(const Ray& r) { return v3(1.0f / r.direction.x, 1.0f / r.direction.y, 1.0f / r.direction.z); }
+
+// ---------------------------------------------------------------- src/primitive/triangle.rs:124-147
+inline bool triangle_intersect_ray(const Ctx& cx, const spt_tri_pos& tp, const Ray& ray, float* t, float* v_out, float* w_out) {
+    cx.c->tris++;
+    Vec3 p0 = v3(tp.p0), p1 = v3(tp.p1), p2 = v3(tp.p2);
+    Vec3 e1 = p1 - p0;
+    Vec3 e2 = p2 - p0;
+    Vec3 q = cross(ray.direction, e2);
+    float det = dot(e1, q);
+    if (det != 0.0f) {
+        det = 1.0f / det;
+        Vec3 s = ray.origin - p0;
+        float v = dot(s, q) * det;
+        if (v >= 0.0f) {
+            Vec3 r = cross(s, e1);
+            float w = dot(ray.direction, r) * det;
+            float u = 1.0f - v - w;
+            if (w >= 0.0f && u >= 0.0f) {
+                *t = dot(e2, r) * det;
+                *v_out = v;
+                *w_out = w;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// triangle.rs:176-218: accept + interpolate (object space)
+inline bool triangle_intersect(const Ctx& cx, uint32_t tri, const Ray& ray, Inter& inter) {
+    float t, v, w;
+    if (triangle_intersect_ray(cx, cx.d->tri_pos[tri], ray, &t, &v, &w)) {
+        if (t > ray.t_min && t < inter.t) {
+            float u = 1.0f - v - w;
+            const spt_tri_attr& a = cx.d->tri_attr[tri];
+            inter.t = t;
+            inter.normal = normalize((v3(a.n[0]) * u + v3(a.n[1]) * v) + v3(a.n[2]) * w);
+            inter.tangent = (v3(a.t[0]) * u + v3(a.t[1]) * v) + v3(a.t[2]) * w;
+            inter.bitangent = (v3(a.b[0]) * u + v3(a.b[1]) * v) + v3(a.b[2]) * w;
+            inter.prim = (int32_t)tri;
+            inter.prim_type = SPT_PRIM_MESH;
+            inter.bv = v;
+            inter.bw = w;
+            return true;
+        }
+    }
+    return false;
+}
+inline bool triangle_intersect_test(const Ctx& cx, uint32_t tri, const Ray& ray, float t_max) {
+    float t, v, w;
+    if (triangle_intersect_ray(cx, cx.d->tri_pos[tri], ray, &t, &v, &w)) return t > ray.t_min && t < t_max;
+    return false;
+}
+
+// ---------------------------------------------------------------- src/primitive/sphere.rs:25-39
+inline bool sphere_intersect_ray(const Ctx& cx, const spt_sphere& s, const Ray& ray, float* mn, float* mx) {
+    cx.c->spheres++;
+    Vec3 oc = ray.origin - v3(s.center);
+    float a = length_squared(ray.direction);
+    float b = dot(ray.direction, oc);
+    float c = length_squared(oc) - s.radius * s.radius;
+    float delta = b * b - a * c;
+    if (delta >= 0.0f) {
+        delta = spt_sqrt(delta);
+        *mn = (-b - delta) / a;
+        *mx = (-b + delta) / a;
+        return true;
+    }
+    return false;
+}
+// sphere.rs:70-82 / 124-134: tangent frame from the unit normal
+inline void sphere_frame(Vec3 norm, Vec3* tangent, Vec3* bitangent) {
+    float sin_theta = spt_sqrt(1.0f - norm.y * norm.y);
+    if (sin_theta != 0.0f) {
+        Vec3 bt = norm * (-norm.y / sin_theta);
+        bt.y = sin_theta;
+        *bitangent = bt;
+        *tangent = cross(bt, norm);
+    } else if (norm.y > 0.0f) {
+        *bitangent = v3(1, 0, 0);
+        *tangent = v3(0, 0, 1);
+    } else {
+        *bitangent = v3(-1, 0, 0);
+        *tangent = v3(0, 0, -1);
+    }
+}
+// sphere.rs:59-84 (texcoords only feed image textures: not computed)
+inline bool sphere_intersect(const Ctx& cx, uint32_t si, const Ray& ray, Inter& inter) {
+    const spt_sphere& s = cx.d->spheres[si];
+    float mn, mx;
+    if (sphere_intersect_ray(cx, s, ray, &mn, &mx)) {
+        float t = (mn < ray.t_min) ? mx : mn;
+        if (ray.t_min < t && t < inter.t) {
+            inter.t = t;
+            Vec3 norm = (point_at(ray, t) - v3(s.center)) / s.radius;
+            inter.normal = norm;
+            sphere_frame(norm, &inter.tangent, &inter.bitangent);
+            inter.prim = (int32_t)si;
+            inter.prim_type = SPT_PRIM_SPHERE;
+            return true;
+        }
+    }
+    return false;
+}
+inline bool sphere_intersect_test(const Ctx& cx, uint32_t si, const Ray& ray, float t_max) {
+    float mn, mx;
+    if (sphere_intersect_ray(cx, cx.d->spheres[si], ray, &mn, &mx)) return mn < t_max && mx > ray.t_min;  // sphere.rs:51-56
+    return false;
+}
+
+// ---------------------------------------------------------------- src/primitive/bvh.rs:237-283 over a BLAS
+constexpr int STACK_MAX = 128;
+inline bool blas_intersect(const Ctx& cx, const spt_mesh& mesh, const Ray& ray, Inter& inter) {
+    bool result = false;
+    if (cx.f.brute) {
+        for (uint32_t i = mesh.tri_first; i < mesh.tri_first + mesh.tri_count; ++i) result |= triangle_intersect(cx, i, ray, inter);
+        return result;
+    }
+    Vec3 inv_d = recip_dir(ray);
+    uint32_t stack[STACK_MAX];
+    int sp = 0;
+    stack[sp++] = mesh.root;
+    while (sp > 0) {
+        const spt_bvh_node& u = cx.d->blas_nodes[stack[--sp]];
+        if (!bbox_intersect_test(cx, u, ray, inv_d, inter.t)) continue;
+        if (u.b & SPT_LEAF_FLAG) {
+            uint32_t n = u.b & ~SPT_LEAF_FLAG;
+            for (uint32_t i = u.a; i < u.a + n; ++i) result |= triangle_intersect(cx, i, ray, inter);
+        } else if (sp + 2 <= STACK_MAX) {
+            stack[sp++] = u.a;  // lc
+            stack[sp++] = u.b;  // rc: popped first
+        }
+    }
+    return result;
+}
+inline bool blas_intersect_test(const Ctx& cx, const spt_mesh& mesh, const Ray& ray, float t_max) {
+    if (cx.f.brute) {
+        for (uint32_t i = mesh.tri_first; i < mesh.tri_first + mesh.tri_count; ++i)
+            if (triangle_intersect_test(cx, i, ray, t_max)) return true;
+        return false;
+    }
+    Vec3 inv_d = recip_dir(ray);
+    uint32_t stack[STACK_MAX];
+    int sp = 0;
+    stack[sp++] = mesh.root;
+    while (sp > 0) {
+        const spt_bvh_node& u = cx.d->blas_nodes[stack[--sp]];
+        if (!bbox_intersect_test(cx, u, ray, inv_d, t_max)) continue;
+        if (u.b & SPT_LEAF_FLAG) {
+            uint32_t n = u.b & ~SPT_LEAF_FLAG;
+            for (uint32_t i = u.a; i < u.a + n; ++i)
+                if (triangle_intersect_test(cx, i, ray, t_max)) return true;
+        } else if (sp + 2 <= STACK_MAX) {
+            stack[sp++] = u.a;
+            stack[sp++] = u.b;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- src/primitive/instance.rs:88-109
+inline Ray transformed_by(const Ray& r, const float* m) {  // src/core/ray.rs:33-41: direction NOT renormalised
+    return Ray{xf_point(m, r.origin), xf_vector(m, r.direction), r.t_min};
+}
+inline bool instance_intersect(const Ctx& cx, uint32_t ii, const Ray& ray, Inter& inter) {
+    cx.c->insts++;
+    const spt_instance& in = cx.d->instances[ii];
+    Ray tr = transformed_by(ray, in.inv);
+    bool hit = (in.prim_type == SPT_PRIM_SPHERE) ? sphere_intersect(cx, in.prim_id, tr, inter)
+                                                 : blas_intersect(cx, cx.d->meshes[in.prim_id], tr, inter);
+    if (hit) {
+        inter.instance = (int32_t)ii;
+        inter.position = point_at(ray, inter.t);
+        inter.normal = normalize(mat3_mul(in.nrm, inter.normal));  // Transform::transform_normal3a
+        inter.tangent = xf_vector(in.fwd, inter.tangent);
+        inter.bitangent = xf_vector(in.fwd, inter.bitangent);
+        return true;
+    }
+    return false;
+}
+inline bool instance_intersect_test(const Ctx& cx, uint32_t ii, const Ray& ray, float t_max) {
+    cx.c->insts++;
+    const spt_instance& in = cx.d->instances[ii];
+    Ray tr = transformed_by(ray, in.inv);
+    return (in.prim_type == SPT_PRIM_SPHERE) ? sphere_intersect_test(cx, in.prim_id, tr, t_max)
+                                             : blas_intersect_test(cx, cx.d->meshes[in.prim_id], tr, t_max);
+}
+
+// ---------------------------------------------------------------- scene.aggregate(): Group (group.rs:24-40) or BvhAccel<Instance>
+bool aggregate_intersect(const Ctx& cx, const Ray& ray, Inter& inter) {
+    cx.c->closest++;
+    const spt_scene_desc& d = *cx.d;
+    bool result = false;
+    if (d.aggregate == SPT_AGGREGATE_GROUP || cx.f.brute) {
+        for (uint32_t i = 0; i < d.n_instances; ++i) result |= instance_intersect(cx, i, ray, inter);
+        return result;
+    }
+    if (d.n_tlas_nodes == 0) return false;
+    Vec3 inv_d = recip_dir(ray);
+    uint32_t stack[STACK_MAX];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const spt_bvh_node& u = d.tlas_nodes[stack[--sp]];
+        if (!bbox_intersect_test(cx, u, ray, inv_d, inter.t)) continue;
+        if (u.b & SPT_LEAF_FLAG) {
+            uint32_t n = u.b & ~SPT_LEAF_FLAG;
+            for (uint32_t i = u.a; i < u.a + n; ++i) result |= instance_intersect(cx, i, ray, inter);
+        } else if (sp + 2 <= STACK_MAX) {
+            stack[sp++] = u.a;
+            stack[sp++] = u.b;
+        }
+    }
+    return result;
+}
+bool aggregate_intersect_test(const Ctx& cx, const Ray& ray, float t_max) {
+    cx.c->shadow++;
+    const spt_scene_desc& d = *cx.d;
+    if (d.aggregate == SPT_AGGREGATE_GROUP || cx.f.brute) {
+        for (uint32_t i = 0; i < d.n_instances; ++i)
+            if (instance_intersect_test(cx, i, ray, t_max)) return true;
+        return false;
+    }
+    if (d.n_tlas_nodes == 0) return false;
+    Vec3 inv_d = recip_dir(ray);
+    uint32_t stack[STACK_MAX];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const spt_bvh_node& u = d.tlas_nodes[stack[--sp]];
+        if (!bbox_intersect_test(cx, u, ray, inv_d, t_max)) continue;
+        if (u.b & SPT_LEAF_FLAG) {
+            uint32_t n = u.b & ~SPT_LEAF_FLAG;
+            for (uint32_t i = u.a; i < u.a + n; ++i)
+                if (instance_intersect_test(cx, i, ray, t_max)) return true;
+        } else if (sp + 2 <= STACK_MAX) {
+            stack[sp++] = u.a;
+            stack[sp++] = u.b;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- src/core/coord.rs:10-59
+struct Coordinate {
+    Vec3 x_world, y_world, z_world, hemisphere;
+    Vec3 to_local(Vec3 w) const { return v3(dot(x_world, w), dot(y_world, w), dot(z_world, w)); }  // transpose * w
+    Vec3 to_world(Vec3 l) const { return (x_world * l.x + y_world * l.y) + z_world * l.z; }
+};
+inline Coordinate coord_from_tangent_normal(Vec3 t, Vec3 n, Vec3 hemisphere) {
+    Coordinate c;
+    c.z_world = n;
+    c.y_world = normalize(cross(c.z_world, t));
+    c.x_world = cross(c.y_world, c.z_world);
+    c.hemisphere = hemisphere;
+    return c;
+}
+
+// src/core/surface.rs:65-95 (no normal map in scope)
+inline Coordinate surface_coord(const spt_surface& s, const Ray& ray, const Inter& inter) {
+    Vec3 shade_normal = inter.normal;
+    bool hit_back = dot(ray.direction, inter.normal) > 0.0f;
+    bool ds = (s.flags & SPT_SURF_DOUBLE_SIDED) != 0;
+    return coord_from_tangent_normal(inter.tangent, (ds && hit_back) ? -shade_normal : shade_normal,
+                                     hit_back ? -inter.normal : inter.normal);
+}
+
+// ---------------------------------------------------------------- src/bxdf/util.rs
+inline float pow2(float x) { return x * x; }
+inline Vec3 reflect(Vec3 i) { return v3(-i.x, -i.y, i.z); }                       // util.rs:3-5
+inline Vec3 reflect_n(Vec3 i, Vec3 n) { return (2.0f * dot(i, n)) * n - i; }     // util.rs:7-9
+inline bool refract(Vec3 i, float ior, Vec3* out) {                              // util.rs:11-24
+    float ior_ratio = (i.z >= 0.0f) ? 1.0f / ior : ior;
+    float o_z_sqr = 1.0f - (1.0f - i.z * i.z) * ior_ratio * ior_ratio;
+    if (o_z_sqr >= 0.0f) {
+        float o_z = (i.z >= 0.0f) ? -spt_sqrt(o_z_sqr) : spt_sqrt(o_z_sqr);
+        *out = v3(-i.x * ior_ratio, -i.y * ior_ratio, o_z);
+        return true;
+    }
+    return false;
+}
+inline bool refract_n(Vec3 i, Vec3 n, float ior, Vec3* out) {                    // util.rs:26-46
+    float cos_i = dot(i, n);
+    if (cos_i >= 0.0f) {
+        float ior_ratio = 1.0f / ior;
+        float o_z_sqr = 1.0f - (1.0f - cos_i * cos_i) * ior_ratio * ior_ratio;
+        if (o_z_sqr >= 0.0f) {
+            *out = (ior_ratio * cos_i - spt_sqrt(o_z_sqr)) * n - ior_ratio * i;
+            return true;
+        }
+        return false;
+    }
+    float ior_ratio = ior;
+    float o_z_sqr = 1.0f - (1.0f - cos_i * cos_i) * ior_ratio * ior_ratio;
+    if (o_z_sqr >= 0.0f) {
+        *out = (spt_sqrt(o_z_sqr) + ior_ratio * cos_i) * n - ior_ratio * i;
+        return true;
+    }
+    return false;
+}
+inline float fresnel_n(float ior, Vec3 i, Vec3 n) {                              // util.rs:56-81
+    float i_ior, o_ior;
+    if (dot(i, n) >= 0.0f) { i_ior = 1.0f; o_ior = ior; } else { i_ior = ior; o_ior = 1.0f; }
+    Vec3 rf;
+    if (refract_n(i, n, ior, &rf)) {
+        float idotn = spt_abs(dot(i, n));
+        float rdotn = spt_abs(dot(rf, n));
+        float denom = i_ior * idotn + o_ior * rdotn;
+        float num = i_ior * idotn - o_ior * rdotn;
+        float rs = num / denom;
+        rs = rs * rs;
+        denom = i_ior * rdotn + o_ior * idotn;
+        num = i_ior * rdotn - o_ior * idotn;
+        float rp = num / denom;
+        rp = rp * rp;
+        return 0.5f * (rs + rp);
+    }
+    return 1.0f;
+}
+inline Color csqrt(Color c) { return col(spt_sqrt(c.r), spt_sqrt(c.g), spt_sqrt(c.b)); }
+inline Color fresnel_conductor_n(Color ior, Color ior_k, Vec3 i, Vec3 n) {       // util.rs:87-112
+    float cosv = dot(i, n);
+    Color ior_ratio, k_ratio;
+    if (cosv >= 0.0f) { ior_ratio = ior; k_ratio = ior_k; } else { ior_ratio = gray(1.0f) / ior; k_ratio = gray(1.0f) / ior_k; }
+    float cos2 = cosv * cosv;
+    float sin2 = 1.0f - cos2;
+    Color ior_ratio2 = ior_ratio * ior_ratio;
+    Color k_ratio2 = k_ratio * k_ratio;
+    Color t0 = ior_ratio2 - k_ratio2 - gray(sin2);
+    Color a2_b2 = csqrt(t0 * t0 + 4.0f * ior_ratio2 * k_ratio2);
+    Color t1 = a2_b2 + gray(cos2);
+    Color a = csqrt(0.5f * (a2_b2 + t0));
+    Color t2 = (2.0f * cosv) * a;
+    Color rs = (t1 - t2) / (t1 + t2);
+    Color t3 = cos2 * a2_b2 + gray(sin2 * sin2);
+    Color t4 = t2 * sin2;
+    Color rp = rs * (t3 - t4) / (t3 + t4);
+    return 0.5f * (rs + rp);
+}
+inline Vec3 half_from_reflect(Vec3 i, Vec3 o) {                                   // util.rs:136-142
+    return (i.z >= 0.0f) ? normalize(i + o) : -normalize(i + o);
+}
+inline Vec3 half_from_refract(Vec3 i, Vec3 o, float ior) {                        // util.rs:144-155
+    Vec3 h = (i.z >= 0.0f) ? normalize(i + ior * o) : normalize(ior * i + o);
+    if (h.z < 0.0f) h = -h;
+    return h;
+}
+inline float ggx_ndf_aniso(Vec3 h, float ax, float ay) {                          // util.rs:162-165
+    return SPT_FRAC_1_PI / spt_max(ax * ay * pow2(pow2(h.x / ax) + pow2(h.y / ay) + pow2(h.z)), 0.0001f);
+}
+inline float smith_g1_aniso(Vec3 v, float ax, float ay) {                         // util.rs:172-174
+    return 2.0f / (1.0f + spt_sqrt(1.0f + (pow2(ax * v.x) + pow2(ay * v.y)) / spt_max(pow2(v.z), 0.0001f)));
+}
+inline float smith_separable_visible_aniso(Vec3 v, Vec3 l, float ax, float ay) {  // util.rs:176-180
+    float vv = spt_abs(v.z) + spt_sqrt(pow2(ax * v.x) + pow2(ay * v.y) + pow2(v.z));
+    float ll = spt_abs(l.z) + spt_sqrt(pow2(ax * l.x) + pow2(ay * l.y) + pow2(l.z));
+    return 1.0f / (vv * ll);
+}
+inline float ggx_smith_vndf_pdf(Vec3 h, Vec3 v, float ax, float ay) {             // util.rs:189-194
+    if (!(v.z >= 0.0f)) v = -v;
+    return smith_g1_aniso(v, ax, ay) * ggx_ndf_aniso(h, ax, ay) * spt_max(dot(v, h), 0.0f) / spt_max(v.z, 0.0001f);
+}
+inline Vec3 ggx_smith_vndf_sample(const Math& m, Vec3 ve, float ax, float ay, float r0, float r1, float* pdf) {  // util.rs:196-224
+    if (!(ve.z >= 0.0f)) ve = -ve;
+    Vec3 vh = normalize(v3(ax * ve.x, ay * ve.y, ve.z));
+    float len_sqr = vh.x * vh.x + vh.y * vh.y;
+    Vec3 t_vec1 = (len_sqr > 0.0f) ? v3(-vh.y, vh.x, 0.0f) / spt_sqrt(len_sqr) : v3(1, 0, 0);
+    Vec3 t_vec2 = cross(vh, t_vec1);
+    float r = spt_sqrt(r0);
+    float phi = 2.0f * SPT_PI * r1;
+    float sp, cp;
+    m.sincos(phi, &sp, &cp);
+    float t1 = r * cp;
+    float t2 = r * sp;
+    float s = 0.5f * (1.0f + vh.z);
+    t2 = (1.0f - s) * spt_sqrt(1.0f - t1 * t1) + s * t2;
+    Vec3 nh = (t1 * t_vec1 + t2 * t_vec2) + spt_sqrt(spt_max(1.0f - t1 * t1 - t2 * t2, 0.0f)) * vh;
+    Vec3 ne = normalize(v3(ax * nh.x, ay * nh.y, spt_max(nh.z, 0.0f)));
+    *pdf = ggx_smith_vndf_pdf(ne, ve, ax, ay);
+    return ne;
+}
+
+// ---------------------------------------------------------------- Bxdf (src/bxdf/mod.rs:72-102)
+enum DirType { REFLECT = 0, TRANSMIT = 1 };
+struct BxdfSample {
+    Vec3 wi;
+    int dir;
+    Color bxdf;
+    float pdf;
+};
+
+inline Color mat_fresnel(const spt_material& mt, Vec3 i, Vec3 n) {  // src/bxdf/fresnel.rs:29-59
+    if (mt.bxdf == SPT_BXDF_MICROFACET_CONDUCTOR || mt.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR)
+        return fresnel_conductor_n(col(mt.c0), col(mt.c1), i, n);
+    return gray(fresnel_n(mt.ior, i, n));
+}
+inline float ndf_visible(const spt_material& mt, Vec3 wo, Vec3 wi, Vec3 h) {  // src/bxdf/microfacet.rs:47-53
+    float ndf = ggx_ndf_aniso(h, mt.ax, mt.ay);
+    float vis = smith_separable_visible_aniso(wo, wi, mt.ax, mt.ay);
+    return ndf * vis;
+}
+
+bool bxdf_is_delta(const spt_material& mt) {
+    return mt.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR || mt.bxdf == SPT_BXDF_SPECULAR_DIELECTRIC || mt.bxdf == SPT_BXDF_PSEUDO;
+}
+
+BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng) {
+    BxdfSample s;
+    switch (mt.bxdf) {
+    case SPT_BXDF_LAMBERT: {  // src/bxdf/lambert.rs:20-36 + rng.rs:72-80
+        float rx, ry;
+        rng.uniform_2d(&rx, &ry);
+        float phi = rx * 2.0f * SPT_PI;
+        float sp, cp;
+        m.sincos(phi, &sp, &cp);
+        float sin_theta = spt_sqrt(ry);
+        float cos_theta = spt_sqrt(1.0f - ry);
+        Vec3 wi = v3(sin_theta * cp, sin_theta * sp, cos_theta);
+        if (wo.z < 0.0f) wi.z = -wi.z;
+        s.wi = wi; s.dir = REFLECT;
+        s.bxdf = col(mt.c0) * SPT_FRAC_1_PI;
+        s.pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
+        return s;
+    }
+    case SPT_BXDF_MICROFACET_CONDUCTOR: {  // src/bxdf/microfacet_conductor.rs:23-42
+        float r0, r1, half_pdf;
+        rng.uniform_2d(&r0, &r1);
+        Vec3 half = ggx_smith_vndf_sample(m, wo, mt.ax, mt.ay, r0, r1, &half_pdf);
+        Color fr = mat_fresnel(mt, wo, half);
+        Vec3 wi = reflect_n(wo, half);
+        s.wi = wi; s.dir = REFLECT;
+        s.bxdf = fr * ndf_visible(mt, wo, wi, half);
+        s.pdf = half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        return s;
+    }
+    case SPT_BXDF_SPECULAR_CONDUCTOR: {  // src/bxdf/specular_conductor.rs:19-36
+        Color fr = mat_fresnel(mt, wo, v3(0, 0, 1));
+        Vec3 wi = reflect(wo);
+        s.wi = wi; s.dir = REFLECT;
+        s.bxdf = fr / spt_abs(wi.z);
+        s.pdf = 1.0f;
+        return s;
+    }
+    case SPT_BXDF_MICROFACET_DIELECTRIC: {  // src/bxdf/microfacet_dielectric.rs:23-86
+        float r0, r1, half_pdf;
+        rng.uniform_2d(&r0, &r1);
+        Vec3 half = ggx_smith_vndf_sample(m, wo, mt.ax, mt.ay, r0, r1, &half_pdf);
+        Color fr = mat_fresnel(mt, wo, half);
+        float reflect_pdf = luminance(fr);
+        Vec3 wi;
+        if (rng.uniform_1d() < reflect_pdf) {
+            wi = reflect_n(wo, half);
+            s.wi = wi; s.dir = REFLECT;
+            s.bxdf = fr * ndf_visible(mt, wo, wi, half);
+            s.pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        } else if (refract_n(wo, half, mt.ior, &wi)) {
+            float ior_ratio = (wo.z >= 0.0f) ? 1.0f / mt.ior : mt.ior;
+            float denom = ior_ratio * dot(wo, half) + dot(wi, half);
+            denom = denom * denom;
+            float num = spt_abs(dot(wi, half));
+            s.pdf = (1.0f - reflect_pdf) * half_pdf * num / denom;
+            num = 4.0f * spt_abs(dot(wo, half)) * spt_abs(dot(wi, half));
+            s.bxdf = (gray(1.0f) - fr) * ndf_visible(mt, wo, wi, half) * num / denom;
+            s.wi = wi; s.dir = TRANSMIT;
+        } else {
+            s.wi = v3(0, 0, 0); s.dir = TRANSMIT; s.bxdf = gray(0.0f); s.pdf = 1.0f;
+        }
+        return s;
+    }
+    case SPT_BXDF_SPECULAR_DIELECTRIC: {  // src/bxdf/specular_dielectric.rs:19-72
+        Color fr = mat_fresnel(mt, wo, v3(0, 0, 1));
+        float reflect_pdf = luminance(fr);
+        Vec3 wi;
+        if (rng.uniform_1d() < reflect_pdf) {
+            wi = reflect(wo);
+            s.wi = wi; s.dir = REFLECT;
+            s.bxdf = fr / spt_abs(wi.z);
+            s.pdf = reflect_pdf;
+        } else if (refract(wo, mt.ior, &wi)) {
+            float ior_ratio = (wo.z >= 0.0f) ? 1.0f / mt.ior : mt.ior;
+            s.wi = wi; s.dir = TRANSMIT;
+            s.bxdf = ior_ratio * ior_ratio * (gray(1.0f) - fr) / spt_abs(wi.z);
+            s.pdf = 1.0f - reflect_pdf;
+        } else {
+            s.wi = v3(0, 0, 0); s.dir = TRANSMIT; s.bxdf = gray(0.0f); s.pdf = 1.0f;
+        }
+        return s;
+    }
+    default: {  // SPT_BXDF_PSEUDO, src/bxdf/pseudo.rs:14-27
+        s.wi = -wo; s.dir = TRANSMIT;
+        s.bxdf = gray(1.0f) / spt_abs(wo.z);
+        s.pdf = 1.0f;
+        return s;
+    }
+    }
+}
+
+float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi) {
+    switch (mt.bxdf) {
+    case SPT_BXDF_LAMBERT:  // lambert.rs:38-44 (1.0, not 0, across hemispheres: quirk Q15)
+        return (wo.z * wi.z >= 0.0f) ? spt_abs(wi.z) * SPT_FRAC_1_PI : 1.0f;
+    case SPT_BXDF_MICROFACET_CONDUCTOR:  // microfacet_conductor.rs:44-53
+        if (wo.z * wi.z >= 0.0f) {
+            Vec3 half = half_from_reflect(wo, wi);
+            float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+            return half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        }
+        return 1.0f;
+    case SPT_BXDF_MICROFACET_DIELECTRIC: {  // microfacet_dielectric.rs:88-113
+        if (wo.z * wi.z >= 0.0f) {
+            Vec3 half = half_from_reflect(wo, wi);
+            float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+            float reflect_pdf = luminance(mat_fresnel(mt, wo, half));
+            return reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        }
+        Vec3 half = half_from_refract(wo, wi, mt.ior);
+        float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+        float reflect_pdf = luminance(mat_fresnel(mt, wo, half));
+        float ior_ratio = (wo.z >= 0.0f) ? 1.0f / mt.ior : mt.ior;
+        float denom = ior_ratio * dot(wo, half) + dot(wi, half);
+        denom = denom * denom;
+        float num = spt_abs(dot(wi, half));
+        return (1.0f - reflect_pdf) * half_pdf * num / denom;
+    }
+    case SPT_BXDF_SPECULAR_DIELECTRIC: {  // specular_dielectric.rs:74-82
+        float reflect_pdf = luminance(mat_fresnel(mt, wo, v3(0, 0, 1)));
+        return (wo.z * wi.z >= 0.0f) ? reflect_pdf : 1.0f - reflect_pdf;
+    }
+    default:  // specular conductor / pseudo
+        return 1.0f;
+    }
+}
+
+Color bxdf_eval(const spt_material& mt, Vec3 wo, Vec3 wi) {
+    switch (mt.bxdf) {
+    case SPT_BXDF_LAMBERT:  // lambert.rs:46-52
+        return (wo.z * wi.z >= 0.0f) ? col(mt.c0) * SPT_FRAC_1_PI : gray(0.0f);
+    case SPT_BXDF_MICROFACET_CONDUCTOR:  // microfacet_conductor.rs:55-64
+        if (wo.z * wi.z >= 0.0f) {
+            Vec3 half = half_from_reflect(wo, wi);
+            return mat_fresnel(mt, wo, half) * ndf_visible(mt, wo, wi, half);
+        }
+        return gray(0.0f);
+    case SPT_BXDF_SPECULAR_CONDUCTOR: {  // specular_conductor.rs:42-50
+        if (dot(wi, reflect(wo)) > 0.999f) return mat_fresnel(mt, wo, v3(0, 0, 1)) / spt_abs(wi.z);
+        return gray(0.0f);
+    }
+    case SPT_BXDF_MICROFACET_DIELECTRIC: {  // microfacet_dielectric.rs:115-138
+        if (wo.z * wi.z >= 0.0f) {
+            Vec3 half = half_from_reflect(wo, wi);
+            return mat_fresnel(mt, wo, half) * ndf_visible(mt, wo, wi, half);
+        }
+        Vec3 half = half_from_refract(wo, wi, mt.ior);
+        Color fr = mat_fresnel(mt, wo, half);
+        float ior_ratio = (wo.z >= 0.0f) ? 1.0f / mt.ior : mt.ior;
+        float denom = ior_ratio * dot(wo, half) + dot(wi, half);
+        denom = denom * denom;
+        float num = 4.0f * spt_abs(dot(wo, half)) * spt_abs(dot(wi, half));
+        return (gray(1.0f) - fr) * ndf_visible(mt, wo, wi, half) * num / denom;
+    }
+    case SPT_BXDF_SPECULAR_DIELECTRIC: {  // specular_dielectric.rs:84-107
+        Color fr = mat_fresnel(mt, wo, v3(0, 0, 1));
+        if (wo.z * wi.z >= 0.0f) {
+            if (dot(wi, reflect(wo)) > 0.999f) return fr / spt_abs(wi.z);
+            return gray(0.0f);
+        }
+        Vec3 ewi;
+        if (refract(wo, mt.ior, &ewi)) {
+            if (dot(wi, ewi) > 0.999f) {
+                float ior_ratio = (wo.z >= 0.0f) ? 1.0f / mt.ior : mt.ior;
+                return ior_ratio * ior_ratio * (gray(1.0f) - fr) / spt_abs(wi.z);
+            }
+        }
+        return gray(0.0f);
+    }
+    default:  // pseudo.rs:32-38
+        if (dot(wo, wi) < -0.999f) return gray(1.0f) / spt_abs(wi.z);
+        return gray(0.0f);
+    }
+}
+
+// ---------------------------------------------------------------- AliasTable::sample (src/core/alias_table.rs:60-68)
+inline uint32_t alias_sample(const spt_alias_table& a, float rand, float* prob) {
+    float temp = rand * (float)a.n;
+    uint32_t x = spt_f2u_sat(temp);
+    float y = temp - (float)x;
+    if (y < a.u[x]) { *prob = a.props[x]; return x; }
+    *prob = a.props[a.k[x]];
+    return a.k[x];
+}
+
+// ---------------------------------------------------------------- lights
+struct LightSample {
+    Vec3 dir;
+    float pdf;
+    Color strength;
+    float dist;
+    bool is_delta;
+};
+
+// EnvLight::strength_dist_pdf(theta, phi) (src/light/environment.rs:51-84), quirk Q5 kept
+inline void env_lookup(const spt_env& e, float theta, float phi, Color* c_out, float* p_out) {
+    int32_t W = (int32_t)e.width, H = (int32_t)e.height;
+    float x = phi * 0.5f * SPT_FRAC_1_PI * (float)e.width;
+    int32_t x1 = spt_f2i_sat(spt_round(x));
+    int32_t x0 = x1 - 1;
+    float xt = x - (float)x0 - 0.5f;
+    uint32_t ux0 = (uint32_t)(x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0));
+    uint32_t ux1 = (uint32_t)(x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1));
+    float y = theta * SPT_FRAC_1_PI * (float)e.height;
+    int32_t y1 = spt_f2i_sat(spt_round(y));
+    int32_t y0 = y1 - 1;
+    float yt = y - (float)y0 - 0.5f;
+    uint32_t uy0 = (uint32_t)(y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0));
+    uint32_t uy1 = (uint32_t)(y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1));
+    auto tex = [&](uint32_t yy, uint32_t xx) { return col(e.texels + 3 * ((size_t)yy * e.width + xx)); };
+    Color c00 = tex(uy0, ux0), c01 = tex(uy1, ux0), c10 = tex(uy0, ux1), c11 = tex(uy1, ux1);
+    Color c0 = c00 * (1.0f - yt) + c01 * yt;
+    Color c1 = c10 * (1.0f - yt) + c11 * yt;
+    Color c = c0 * (1.0f - xt) + c1 * xt;
+    float p00 = e.alias.props[(size_t)uy0 * e.width + ux0], p01 = e.alias.props[(size_t)uy1 * e.width + ux0];
+    float p10 = e.alias.props[(size_t)uy0 * e.width + ux1], p11 = e.alias.props[(size_t)uy1 * e.width + ux1];
+    float p0 = p00 * (1.0f - yt) + p01 * yt;
+    float p1 = p10 * (1.0f - yt) + p11 * yt;
+    float p = p0 * (1.0f - xt) * p1 * xt;
+    *c_out = c * col(e.scale);
+    *p_out = p;
+}
+// LightT::strength_dist_pdf for the env (environment.rs:128-133)
+inline void env_strength_pdf(const Ctx& cx, Vec3 wi, Color* c, float* pdf) {
+    float theta = cx.m.acos(wi.y);
+    float phi = cx.m.atan2(wi.x, wi.z) + SPT_PI;
+    env_lookup(cx.d->env, theta, phi, c, pdf);
+}
+
+// Instance::sample (src/primitive/instance.rs:111-129) over Sphere::sample / BvhAccel<Triangle>::sample
+struct ShapeSample {
+    Vec3 position, normal, tangent, bitangent;
+    float pdf;
+};
+inline ShapeSample instance_sample(const Ctx& cx, const spt_instance& in, Rng& rng) {
+    ShapeSample s;
+    float pdf;
+    if (in.prim_type == SPT_PRIM_SPHERE) {  // sphere.rs:103-136 + rng.rs:58-65
+        const spt_sphere& sp = cx.d->spheres[in.prim_id];
+        float rx, ry;
+        rng.uniform_2d(&rx, &ry);
+        float phi = rx * 2.0f * SPT_PI;
+        float sphi, cphi;
+        cx.m.sincos(phi, &sphi, &cphi);
+        float cos_theta = 1.0f - 2.0f * ry;
+        float sin_theta = spt_sqrt(1.0f - cos_theta * cos_theta);
+        Vec3 norm = v3(sin_theta * cphi, sin_theta * sphi, cos_theta);
+        s.position = v3(sp.center) + norm * sp.radius;
+        s.normal = norm;
+        sphere_frame(norm, &s.tangent, &s.bitangent);
+        pdf = 0.25f * SPT_FRAC_1_PI;
+    } else {  // bvh.rs:293-298 + triangle.rs:224-271
+        const spt_mesh& mesh = cx.d->meshes[in.prim_id];
+        float fi = rng.uniform_1d() * (float)mesh.tri_count;
+        uint32_t idx = spt_f2u_sat(fi);
+        if (idx > mesh.tri_count - 1) idx = mesh.tri_count - 1;
+        uint32_t tri = mesh.tri_first + idx;
+        float r0, r1;
+        rng.uniform_2d(&r0, &r1);
+        float r0_sqrt = spt_sqrt(r0);
+        float u = 1.0f - r0_sqrt;
+        float v = r0_sqrt * (1.0f - r1);
+        float w = 1.0f - u - v;
+        const spt_tri_pos& tp = cx.d->tri_pos[tri];
+        const spt_tri_attr& a = cx.d->tri_attr[tri];
+        Vec3 p0 = v3(tp.p0), p1 = v3(tp.p1), p2 = v3(tp.p2);
+        s.position = (p0 * u + p1 * v) + p2 * w;
+        float area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
+        s.normal = (v3(a.n[0]) * u + v3(a.n[1]) * v) + v3(a.n[2]) * w;
+        s.tangent = (v3(a.t[0]) * u + v3(a.t[1]) * v) + v3(a.t[2]) * w;
+        s.bitangent = (v3(a.b[0]) * u + v3(a.b[1]) * v) + v3(a.b[2]) * w;
+        pdf = (1.0f / spt_max(area, 0.001f)) / (float)mesh.tri_count;
+    }
+    float original_area = length(cross(s.tangent, s.bitangent));
+    s.position = xf_point(in.fwd, s.position);
+    s.normal = normalize(mat3_mul(in.nrm, s.normal));
+    s.bitangent = xf_vector(in.fwd, s.bitangent);
+    s.tangent = xf_vector(in.fwd, s.tangent);
+    float transformed_area = length(cross(s.tangent, s.bitangent));
+    s.pdf = pdf * original_area / transformed_area;
+    return s;
+}
+// Instance::pdf (instance.rs:131-141) over Triangle::pdf (triangle.rs:273-281) / Sphere::pdf
+inline float instance_pdf(const Ctx& cx, const spt_instance& in, const Inter& inter) {
+    Vec3 tangent = xf_vector(in.inv, inter.tangent);
+    Vec3 bitangent = xf_vector(in.inv, inter.bitangent);
+    float original_area = length(cross(tangent, bitangent));
+    float transformed_area = length(cross(inter.tangent, inter.bitangent));
+    float prim_pdf;
+    if (in.prim_type == SPT_PRIM_SPHERE) {
+        prim_pdf = 0.25f * SPT_FRAC_1_PI;
+    } else {
+        const spt_mesh& mesh = cx.d->meshes[in.prim_id];
+        const spt_tri_pos& tp = cx.d->tri_pos[inter.prim];
+        Vec3 p0 = v3(tp.p0), p1 = v3(tp.p1), p2 = v3(tp.p2);
+        float area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
+        prim_pdf = (1.0f / spt_max(area, 0.001f)) / (float)mesh.tri_count;
+    }
+    return prim_pdf * original_area / transformed_area;
+}
+
+// LightT::sample for every light type
+inline void light_sample(const Ctx& cx, const spt_light& l, Vec3 position, Rng& rng, LightSample* out) {
+    switch (l.type) {
+    case SPT_LIGHT_DIRECTIONAL:  // directional.rs:26-29
+        out->dir = -v3(l.dir); out->pdf = 1.0f; out->strength = col(l.strength); out->dist = SPT_F32_MAX; out->is_delta = true;
+        return;
+    case SPT_LIGHT_POINT: {  // point.rs:23-29
+        Vec3 sv = v3(l.pos) - position;
+        float dist_sqr = length_squared(sv);
+        float dist = spt_sqrt(dist_sqr);
+        out->dir = sv / dist; out->pdf = 1.0f; out->strength = col(l.strength) / dist_sqr; out->dist = dist; out->is_delta = true;
+        return;
+    }
+    case SPT_LIGHT_SPOT: {  // spot.rs:50-65
+        Vec3 sv = v3(l.pos) - position;
+        float dist_sqr = length_squared(sv);
+        float dist = spt_sqrt(dist_sqr);
+        sv = sv / dist;
+        float atten = spt_clamp((dot(v3(l.dir), -sv) - l.cos_outer) / spt_max(l.cos_inner - l.cos_outer, 0.0001f), 0.0f, 1.0f);
+        out->dir = sv; out->pdf = 1.0f; out->strength = (col(l.strength) * atten) / dist_sqr; out->dist = dist; out->is_delta = true;
+        return;
+    }
+    case SPT_LIGHT_SHAPE: {  // shape_light.rs:20-42
+        const spt_instance& in = cx.d->instances[l.instance];
+        const spt_surface& sf = cx.d->surfaces[in.surface];
+        ShapeSample s = instance_sample(cx, in, rng);
+        Color emissive = col(sf.emissive);
+        Vec3 light_vec = s.position - position;
+        float dist_sqr = length_squared(light_vec);
+        float dist = spt_sqrt(dist_sqr);
+        Vec3 light_dir = light_vec / dist;
+        float cosv;
+        if (sf.flags & SPT_SURF_DOUBLE_SIDED) {
+            cosv = spt_abs(dot(light_dir, s.normal));
+        } else {
+            cosv = dot(light_dir, -s.normal);
+            if (!(cosv > 0.0f)) { cosv = 1.0f; emissive = gray(0.0f); }
+        }
+        out->dir = light_dir; out->pdf = s.pdf * dist_sqr / spt_max(cosv, 0.001f); out->strength = emissive; out->dist = dist; out->is_delta = false;
+        return;
+    }
+    default: {  // SPT_LIGHT_ENV, environment.rs:110-126
+        const spt_env& e = cx.d->env;
+        float pr;
+        uint32_t ind = alias_sample(e.alias, rng.uniform_1d(), &pr);
+        uint32_t x = ind % e.width, y = ind / e.width;
+        float rx, ry;
+        rng.uniform_2d(&rx, &ry);
+        float theta = ((float)y + ry) / (float)e.height * SPT_PI;
+        float phi = ((float)x + rx) / (float)e.width * 2.0f * SPT_PI;
+        float st, ct, sp, cp;
+        cx.m.sincos(theta, &st, &ct);
+        cx.m.sincos(phi, &sp, &cp);
+        out->dir = v3(st * sp, ct, st * cp);
+        env_lookup(e, theta, phi, &out->strength, &out->pdf);
+        out->dist = spt_inf(); out->is_delta = false;
+        return;
+    }
+    }
+}
+
+// LightSamplerT::sample_light (uniform.rs:28-41, power_is.rs:49-59); false when the scene has no light (D5)
+inline bool sample_light(const Ctx& cx, Vec3 position, Rng& rng, LightSample* out) {
+    const spt_scene_desc& d = *cx.d;
+    if (d.n_lights == 0) return false;
+    if (d.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) {
+        float pr;
+        uint32_t index = alias_sample(d.light_alias, rng.uniform_1d(), &pr);
+        light_sample(cx, d.lights[index], position, rng, out);
+        out->pdf = pr * out->pdf;
+    } else {
+        float fi = rng.uniform_1d() * (float)d.n_lights;
+        uint32_t index = spt_f2u_sat(fi);
+        if (index > d.n_lights - 1) index = d.n_lights - 1;
+        light_sample(cx, d.lights[index], position, rng, out);
+        out->pdf = out->pdf * (1.0f / (float)d.n_lights);
+    }
+    return true;
+}
+// pdf_shape_light (uniform.rs:43-68, power_is.rs:61-88)
+inline float pdf_shape_light(const Ctx& cx, Vec3 position, const Inter& inter) {
+    const spt_scene_desc& d = *cx.d;
+    const spt_instance& in = d.instances[inter.instance];
+    const spt_surface& sf = d.surfaces[in.surface];
+    float primitive_pdf = instance_pdf(cx, in, inter);
+    Vec3 light_vec = inter.position - position;
+    float dist_sqr = length_squared(light_vec);
+    Vec3 light_dir = light_vec / spt_sqrt(dist_sqr);
+    float cosv;
+    if (sf.flags & SPT_SURF_DOUBLE_SIDED) {
+        cosv = spt_abs(dot(light_dir, inter.normal));
+    } else {
+        cosv = dot(light_dir, -inter.normal);
+        if (!(cosv > 0.0f)) cosv = 1.0f;
+    }
+    float local_pdf = primitive_pdf * dist_sqr / spt_max(cosv, 0.00001f);
+    if (d.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) return local_pdf * d.light_alias.props[in.light];
+    return local_pdf * (1.0f / (float)d.n_lights);
+}
+// pdf_env_light (uniform.rs:70-76, power_is.rs:90-96 with the true env index, quirk Q6)
+inline float pdf_env_light(const Ctx& cx) {
+    const spt_scene_desc& d = *cx.d;
+    if (d.env_light_index < 0) return 1.0f;
+    if (d.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) return d.light_alias.props[d.env_light_index];
+    return 1.0f / (float)d.n_lights;
+}
+
+// ---------------------------------------------------------------- src/medium/{homogeneous,util}.rs
+inline float henyey_greenstein(float g, float cosv) {  // util.rs:1-7
+    float g2 = g * g;
+    float denom = 1.0f + g2 + 2.0f * g * cosv;
+    denom = denom * spt_sqrt(denom);
+    return 0.25f * SPT_FRAC_1_PI * (1.0f - g2) / denom;
+}
+inline float henyey_greenstein_cdf_inverse(float g, float rand) {  // util.rs:9-18
+    if (spt_abs(g) < 0.01f) return 1.0f - 2.0f * rand;
+    float g2 = g * g;
+    float temp = (1.0f - g2) / (1.0f - g + 2.0f * g * rand);
+    return 0.5f * (1.0f + g2 - temp * temp) / g;
+}
+inline Vec3 hg_local_to_world(Vec3 wo_world, Vec3 wi_local) {  // util.rs:20-30
+    Vec3 v = (spt_abs(wo_world.y) < 0.99f) ? v3(0, 1, 0) : v3(1, 0, 0);
+    Vec3 u = normalize(cross(v, wo_world));
+    v = cross(wo_world, u);
+    return (u * wi_local.x + v * wi_local.y) + wo_world * wi_local.z;
+}
+// Homogeneous::sample_pi (homogeneous.rs:30-58)
+inline void medium_sample_pi(const Ctx& cx, const spt_medium& md, Vec3 po, Vec3 wo, float t_max, Rng& rng, Vec3* pi, bool* still_in, Color* atten_out) {
+    float rx, ry;
+    rng.uniform_2d(&rx, &ry);
+    float sample_sigma_t = (rx < 1.0f / 3.0f) ? md.sigma_t[0] : ((rx < 2.0f / 3.0f) ? md.sigma_t[1] : md.sigma_t[2]);
+    float sample_t = -cx.m.ln(1.0f - ry) / sample_sigma_t;
+    Color sigma_t = col(md.sigma_t);
+    float tt = spt_min(sample_t, t_max);
+    Color attenuation = cx.m.exp((-sigma_t) * tt);
+    *pi = po - wo * tt;
+    if (sample_t < t_max) {
+        float atten_pdf = avg(sigma_t * attenuation);
+        *still_in = true;
+        *atten_out = attenuation * col(md.sigma_s) / atten_pdf;
+    } else {
+        float atten_pdf = avg(attenuation);
+        *still_in = false;
+        *atten_out = attenuation / atten_pdf;
+    }
+}
+// Homogeneous::sample_wi (homogeneous.rs:60-70)
+inline Vec3 medium_sample_wi(const Ctx& cx, const spt_medium& md, Vec3 wo, Rng& rng, float* pdf) {
+    float rx, ry;
+    rng.uniform_2d(&rx, &ry);
+    float cos_theta = henyey_greenstein_cdf_inverse(md.g, rx);
+    float sin_theta = spt_sqrt(1.0f - cos_theta * cos_theta);
+    float phi = 2.0f * SPT_PI * ry;
+    float sp, cp;
+    cx.m.sincos(phi, &sp, &cp);
+    Vec3 wi = hg_local_to_world(wo, v3(sin_theta * cp, sin_theta * sp, cos_theta));
+    *pdf = henyey_greenstein(md.g, cos_theta);
+    return wi;
+}
+
+// ---------------------------------------------------------------- src/renderer/pt.rs
+inline float power_heuristic(float p0, float p1) {  // pt.rs:298-302 with n0 = n1 = 1
+    float prod0 = 1.0f * p0;
+    float prod1 = 1.0f * p1;
+    return prod0 * prod0 / (prod0 * prod0 + prod1 * prod1);
+}
+
+// pt.rs:212-233.  `medium_primitive` is the raw Triangle / Sphere last hit, intersected with the
+// WORLD-space shadow ray, i.e. without its instance transform (reference behaviour, kept).
+inline Ray shadow_ray_from_medium(const Ctx& cx, Vec3 p, Vec3 light_dir, float light_dist, int prim_type, int prim, float* transported) {
+    Ray shadow_ray = make_ray(p, light_dir);
+    Inter temp;
+    temp.t = light_dist - 0.001f;
+    bool hit = false;
+    if (prim_type == SPT_PRIM_MESH) hit = triangle_intersect(cx, (uint32_t)prim, shadow_ray, temp);
+    else if (prim_type == SPT_PRIM_SPHERE) hit = sphere_intersect(cx, (uint32_t)prim, shadow_ray, temp);
+    if (hit) {
+        *transported = temp.t;
+        shadow_ray.t_min += temp.t;
+    } else {
+        *transported = light_dist;
+        shadow_ray.t_min += light_dist - 0.001f;
+    }
+    return shadow_ray;
+}
+
+// PathTracer::trace_ray (pt.rs:39-210)
+Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
+    const spt_scene_desc& d = *cx.d;
+    Color final_color = gray(0.0f);
+    Color throughput = gray(1.0f);
+    uint32_t curr_depth = 0;
+    int32_t curr_medium = -1;
+    Vec3 lsi_position = v3(0, 0, 0);  // light_sampler_inputs (normal is never read)
+    float last_sample_pdf = 0.0f;
+
+    while (curr_depth < max_depth) {
+        Inter inter;
+        bool does_hit = aggregate_intersect(cx, ray, inter);
+
+        if (curr_medium >= 0) {  // pt.rs:56-96
+            const spt_medium& md = d.mediums[curr_medium];
+            Vec3 wo = -ray.direction;
+            Vec3 pi;
+            bool still_in;
+            Color attenuation;
+            medium_sample_pi(cx, md, ray.origin, wo, inter.t, rng, &pi, &still_in, &attenuation);
+            throughput = throughput * attenuation;
+            if (!still_in) {
+                curr_medium = -1;
+                continue;
+            }
+            Color li = gray(0.0f);
+            lsi_position = pi;
+            LightSample ls;
+            if (sample_light(cx, lsi_position, rng, &ls)) {
+                float phase = henyey_greenstein(md.g, dot(wo, ls.dir));
+                float transported;
+                Ray shadow_ray = shadow_ray_from_medium(cx, pi, ls.dir, ls.dist, inter.prim_type, inter.prim, &transported);
+                Color atten = cx.m.exp((-col(md.sigma_t)) * transported);
+                if (ls.pdf != 0.0f && spt_is_finite(ls.pdf) && !aggregate_intersect_test(cx, shadow_ray, ls.dist - 0.001f)) {
+                    if (ls.is_delta) {
+                        li = atten * phase * ls.strength / ls.pdf;
+                    } else {
+                        float weight = power_heuristic(ls.pdf, phase);
+                        li = atten * phase * ls.strength * weight / ls.pdf;
+                    }
+                }
+            }
+            final_color = final_color + throughput * li;
+            float pdf;
+            Vec3 wi = medium_sample_wi(cx, md, wo, rng, &pdf);
+            last_sample_pdf = pdf;
+            ray = make_ray(pi, wi);
+        } else if (!does_hit) {  // pt.rs:97-111
+            if (d.env.width != 0) {
+                Color env;
+                float env_pdf;
+                env_strength_pdf(cx, ray.direction, &env, &env_pdf);
+                float weight = 1.0f;
+                if (curr_depth != 0) {
+                    float pdf = pdf_env_light(cx) * env_pdf;
+                    weight = power_heuristic(last_sample_pdf, pdf);
+                }
+                final_color = final_color + throughput * env * weight;
+            }
+            break;
+        } else {  // pt.rs:112-193
+            Vec3 po = point_at(ray, inter.t);
+            const spt_instance& in = d.instances[inter.instance];
+            const spt_surface& surf = d.surfaces[in.surface];
+            const spt_material& mt = d.materials[surf.material];
+            Coordinate coord_po = surface_coord(surf, ray, inter);
+
+            Color li_emissive = col(surf.emissive);
+            if (luminance(li_emissive) > 0.0f) {
+                float weight = 1.0f;
+                if (curr_depth != 0) {
+                    float pdf = pdf_shape_light(cx, lsi_position, inter);
+                    weight = power_heuristic(last_sample_pdf, pdf);
+                }
+                final_color = final_color + throughput * li_emissive * weight;
+            }
+
+            Vec3 wo = coord_po.to_local(-ray.direction);
+            BxdfSample samp = bxdf_sample(cx.m, mt, wo, rng);
+
+            Color li = gray(0.0f);
+            lsi_position = po;
+            if (!bxdf_is_delta(mt)) {
+                LightSample ls;
+                if (sample_light(cx, lsi_position, rng, &ls)) {
+                    Vec3 wi = coord_po.to_local(ls.dir);
+                    Color f = bxdf_eval(mt, wo, wi);
+                    float mat_pdf = bxdf_pdf(mt, wo, wi);
+                    Ray shadow_ray = make_ray(po, ls.dir);
+                    shadow_ray.t_min = T_MIN_EPS / spt_max(spt_abs(wi.z), 0.00001f);
+                    if (ls.pdf != 0.0f && spt_is_finite(ls.pdf) && !aggregate_intersect_test(cx, shadow_ray, ls.dist - 0.001f)) {
+                        if (ls.is_delta) {
+                            li = ls.strength * f * spt_abs(wi.z) / spt_max(ls.pdf, 0.00001f);
+                        } else {
+                            float weight = power_heuristic(ls.pdf, mat_pdf);
+                            li = ls.strength * f * spt_abs(wi.z) * weight / spt_max(ls.pdf, 0.00001f);
+                        }
+                    }
+                }
+                final_color = final_color + throughput * li;
+            }
+
+            last_sample_pdf = samp.pdf;
+            Vec3 wi_world = coord_po.to_world(samp.wi);
+            ray = make_ray(po, wi_world);
+            ray.t_min = T_MIN_EPS / spt_max(spt_abs(samp.wi.z), 0.00001f);
+            throughput = throughput * (samp.bxdf * spt_abs(samp.wi.z) / spt_max(samp.pdf, 0.00001f));
+            // Coordinate::in_expected_hemisphere (coord.rs:53-59)
+            float hd = dot(wi_world, coord_po.hemisphere);
+            if (!((samp.dir == REFLECT) ? (hd >= 0.0f) : (hd <= 0.0f))) break;
+            if (dot(wi_world, inter.normal) < 0.0f) {
+                // Surface::inside_medium (surface.rs:105-111): none when double sided
+                curr_medium = (surf.flags & SPT_SURF_DOUBLE_SIDED) ? -1 : surf.inside_medium;
+            }
+        }
+
+        if (!is_finite(throughput)) break;
+        float rr_rand = rng.uniform_1d();
+        float rr_prop = spt_clamp(luminance(throughput), 0.001f, 0.95f);
+        if (rr_rand > rr_prop) break;
+        throughput = throughput * (1.0f / rr_prop);  // DivAssign<f32>: multiply by the reciprocal
+        curr_depth += 1;
+    }
+    return final_color;
+}
+
+// PerspectiveCamera::generate_ray (src/camera/perspective.rs:40-47)
+inline Ray camera_ray(const spt_camera& c, float x, float y) {
+    Vec3 dir = normalize((v3(c.forward) * c.half_cot_half_fov + v3(c.right) * x) + v3(c.up) * y);
+    return make_ray(v3(c.eye), dir);
+}
+
+// pixel sampler (src/pixel_sampler/{random,jittered,recurrence}.rs); jittered: the reference's end
+// test never fires (jittered.rs:47), the evident division_x*division_y samples are produced.
+inline void pixel_offset(const spt_render_params& p, uint32_t pixel, uint32_t s, Rng& rng, float* ox, float* oy) {
+    if (p.sampler == SPT_SAMPLER_RECURRENCE) {
+        spt_r2_offset(pixel, p.spp, s, ox, oy);
+    } else if (p.sampler == SPT_SAMPLER_JITTERED) {
+        uint32_t ix = s % p.division_x, iy = s / p.division_x;
+        float inv_x = 1.0f / (float)p.division_x, inv_y = 1.0f / (float)p.division_y;
+        *ox = ((float)ix + rng.uniform_1d()) * inv_x;
+        *oy = ((float)iy + rng.uniform_1d()) * inv_y;
+    } else {
+        *ox = rng.uniform_1d();
+        *oy = rng.uniform_1d();
+    }
+}
+
+bool row_in_shard(const spt_render_params& p, uint32_t j) {
+    uint32_t sc = p.shard_count ? p.shard_count : 1, sr = p.strip_rows ? p.strip_rows : 1;
+    return (j / sr) % sc == p.shard_index;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C interface (oracle.h)
+extern "C" {
+
+// PathTracer::render (pt.rs:237-296): threads over contiguous row bands (util.rs:6-19)
+int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_render_params* params, uint32_t flags,
+                  int32_t n_threads, float* rgb_mean_out, oracle_stats* stats) {
+    if (!desc || !cam || !params || !rgb_mean_out) return 1;
+    const spt_render_params p = *params;
+    if (p.width == 0 || p.height == 0 || p.spp == 0) return 1;
+    if (p.sampler == SPT_SAMPLER_JITTERED && (p.division_x == 0 || p.division_x * p.division_y != p.spp)) return 1;
+    std::vector<uint32_t> rows;
+    for (uint32_t j = 0; j < p.height; ++j)
+        if (row_in_shard(p, j)) rows.push_back(j);
+    if (n_threads <= 0) n_threads = (int32_t)std::thread::hardware_concurrency() * 2;  // pt.rs:243
+    if (n_threads < 1) n_threads = 1;
+    uint32_t nrows = (uint32_t)rows.size();
+    if ((uint32_t)n_threads > nrows && nrows > 0) n_threads = (int32_t)nrows;
+    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0};
+    std::vector<Counters> counters((size_t)n_threads);
+    const float aspect = (float)p.width / (float)p.height;
+    const float width_inv = 1.0f / (float)p.width, height_inv = 1.0f / (float)p.height;
+    auto work = [&](int t) {
+        Ctx cx{desc, f, Math{f.libm}, &counters[(size_t)t]};
+        uint32_t per = nrows / (uint32_t)n_threads;
+        uint32_t from = (uint32_t)t * per, to = (t + 1 == n_threads) ? nrows : (uint32_t)(t + 1) * per;
+        for (uint32_t rr = from; rr < to; ++rr) {
+            uint32_t j = rows[rr];
+            for (uint32_t i = 0; i < p.width; ++i) {
+                uint32_t pixel = j * p.width + i;
+                Color sum = gray(0.0f);
+                for (uint32_t s = 0; s < p.spp; ++s) {
+                    Rng rng{spt_rng_seed(p.seed, pixel, s)};
+                    float ox, oy;
+                    pixel_offset(p, pixel, s, rng, &ox, &oy);
+                    float x = (((float)i + ox) * width_inv - 0.5f) * aspect;             // pt.rs:269
+                    float y = ((float)(p.height - j - 1) + oy) * height_inv - 0.5f;      // pt.rs:270-271
+                    Ray ray = camera_ray(*cam, x, y);
+                    Color c = trace_ray(cx, ray, rng, p.max_depth);
+                    sum = sum + c;  // film.rs:87: color += sample.color
+                }
+                Color mean = sum / (float)p.spp;  // film.rs:91: color / weight_sum
+                float* o = rgb_mean_out + ((size_t)rr * p.width + i) * 3;
+                o[0] = mean.r; o[1] = mean.g; o[2] = mean.b;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->samples = (uint64_t)nrows * p.width * p.spp;
+        stats->threads = (uint32_t)n_threads;
+        for (auto& c : counters) {
+            stats->segments_closest += c.closest; stats->segments_shadow += c.shadow;
+            stats->node_tests += c.nodes; stats->tri_tests += c.tris; stats->sphere_tests += c.spheres;
+            stats->instance_visits += c.insts;
+        }
+    }
+    return 0;
+}
+
+int oracle_trace_closest(const spt_scene_desc* desc, uint32_t flags, uint32_t n, const spt_ray* rays, spt_hit* hits) {
+    if (!desc || (!rays && n) || (!hits && n)) return 1;
+    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0};
+    Counters c;
+    Ctx cx{desc, f, Math{f.libm}, &c};
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r{v3(rays[i].o), v3(rays[i].d), rays[i].t_min};
+        Inter inter;
+        inter.t = rays[i].t_max;
+        bool hit = aggregate_intersect(cx, r, inter);
+        hits[i].t = hit ? inter.t : SPT_F32_MAX;
+        hits[i].instance = hit ? inter.instance : -1;
+        hits[i].prim = hit ? inter.prim : -1;
+        hits[i].v = hit ? inter.bv : 0.0f;
+        hits[i].w = hit ? inter.bw : 0.0f;
+    }
+    return 0;
+}
+
+int oracle_trace_any(const spt_scene_desc* desc, uint32_t flags, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
+    if (!desc || (!rays && n) || (!occluded && n)) return 1;
+    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0};
+    Counters c;
+    Ctx cx{desc, f, Math{f.libm}, &c};
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r{v3(rays[i].o), v3(rays[i].d), rays[i].t_min};
+        occluded[i] = aggregate_intersect_test(cx, r, rays[i].t_max) ? 1 : 0;
+    }
+    return 0;
+}
+
+// ---- unit seams for known-answer tests ------------------------------------------------
+void oracle_bxdf_sample(const spt_material* mt, const float wo[3], uint64_t rng_state, uint32_t flags, float wi_out[3],
+                        float bxdf_out[3], float* pdf_out, int32_t* dir_out) {
+    Rng rng{{rng_state}};
+    BxdfSample s = bxdf_sample(Math{(flags & ORACLE_LIBM) != 0}, *mt, v3(wo), rng);
+    wi_out[0] = s.wi.x; wi_out[1] = s.wi.y; wi_out[2] = s.wi.z;
+    bxdf_out[0] = s.bxdf.r; bxdf_out[1] = s.bxdf.g; bxdf_out[2] = s.bxdf.b;
+    *pdf_out = s.pdf;
+    *dir_out = s.dir;
+}
+void oracle_bxdf_eval(const spt_material* mt, const float wo[3], const float wi[3], float bxdf_out[3], float* pdf_out) {
+    Color f = bxdf_eval(*mt, v3(wo), v3(wi));
+    bxdf_out[0] = f.r; bxdf_out[1] = f.g; bxdf_out[2] = f.b;
+    *pdf_out = bxdf_pdf(*mt, v3(wo), v3(wi));
+}
+float oracle_fresnel_dielectric(float ior, const float i[3], const float n[3]) { return fresnel_n(ior, v3(i), v3(n)); }
+float oracle_henyey_greenstein(float g, float c) { return henyey_greenstein(g, c); }
+float oracle_hg_cdf_inverse(float g, float r) { return henyey_greenstein_cdf_inverse(g, r); }
+uint32_t oracle_alias_sample(const spt_alias_table* a, float rand, float* prob) { return alias_sample(*a, rand, prob); }
+void oracle_env_lookup(const spt_scene_desc* d, const float wi[3], float rgb[3], float* pdf) {
+    Counters c;
+    Ctx cx{d, Flags{false, false, false}, Math{false}, &c};
+    Color col_;
+    env_strength_pdf(cx, v3(wi), &col_, pdf);
+    rgb[0] = col_.r; rgb[1] = col_.g; rgb[2] = col_.b;
+}
+void oracle_camera_ray(const spt_camera* cam, float x, float y, float o[3], float dir[3]) {
+    Ray r = camera_ray(*cam, x, y);
+    o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z;
+    dir[0] = r.direction.x; dir[1] = r.direction.y; dir[2] = r.direction.z;
+}
+
+// shared-spec functions of include/spt_detmath.h, exported for tests/test_detmath.py
+void oracle_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        switch (fn) {
+        case 0: out[i] = spt_sin(a[i]); break;
+        case 1: out[i] = spt_cos(a[i]); break;
+        case 2: out[i] = spt_log(a[i]); break;
+        case 3: out[i] = spt_exp(a[i]); break;
+        case 4: out[i] = spt_acos(a[i]); break;
+        case 5: out[i] = spt_atan2(a[i], b[i]); break;
+        case 6: out[i] = spt_asin(a[i]); break;
+        case 7: out[i] = spt_round(a[i]); break;
+        case 8: out[i] = spt_floor(a[i]); break;
+        default: out[i] = 0.0f; break;
+        }
+    }
+}
+void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out) {
+    spt_rng r = spt_rng_seed(seed, pixel, sample);
+    for (uint32_t i = 0; i < n; ++i) out[i] = spt_rng_f32(&r);
+}
+uint64_t oracle_rng_state(uint64_t seed, uint32_t pixel, uint32_t sample) { return spt_rng_seed(seed, pixel, sample).state; }
+void oracle_r2_offsets(uint32_t pixel, uint32_t spp, uint32_t n, float* out) {
+    for (uint32_t s = 0; s < n; ++s) spt_r2_offset(pixel, spp, s, &out[2 * s], &out[2 * s + 1]);
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+/*
+ * oracle.h — C interface of the CPU oracle (oracle/liboracle.so).
+ * TEST INFRASTRUCTURE ONLY: see the header of oracle.cpp.  It consumes the same
+ * flattened scene (include/spt_abi.h) that the HIP library receives.
+ */
+#ifndef SPT_ORACLE_H
+#define SPT_ORACLE_H
+#include <stdint.h>
+
+#include "../include/spt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ORACLE_SLAB_RECIPROCAL = 1u, /* slab test with a precomputed 1/d, as the kernels do (default: divide, bbox.rs:68-79) */
+    ORACLE_BRUTE_FORCE = 2u,     /* ignore TLAS and BLAS: linear scan of instances and triangles */
+    ORACLE_LIBM = 4u             /* libm sin/cos/log/exp/acos/atan2 instead of include/spt_detmath.h */
+};
+
+typedef struct oracle_stats {
+    uint64_t samples, segments_closest, segments_shadow;
+    uint64_t node_tests, tri_tests, sphere_tests, instance_visits;
+    uint32_t threads;
+    uint32_t pad;
+} oracle_stats;
+
+/* n_threads <= 0: 2 x hardware_concurrency, the reference's layout (src/renderer/pt.rs:243). */
+int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_render_params* params, uint32_t flags,
+                  int32_t n_threads, float* rgb_mean_out, oracle_stats* stats);
+int oracle_trace_closest(const spt_scene_desc* desc, uint32_t flags, uint32_t n, const spt_ray* rays, spt_hit* hits);
+int oracle_trace_any(const spt_scene_desc* desc, uint32_t flags, uint32_t n, const spt_ray* rays, uint8_t* occluded);
+
+void oracle_bxdf_sample(const spt_material* mt, const float wo[3], uint64_t rng_state, uint32_t flags, float wi_out[3],
+                        float bxdf_out[3], float* pdf_out, int32_t* dir_out);
+void oracle_bxdf_eval(const spt_material* mt, const float wo[3], const float wi[3], float bxdf_out[3], float* pdf_out);
+float oracle_fresnel_dielectric(float ior, const float i[3], const float n[3]);
+float oracle_henyey_greenstein(float g, float c);
+float oracle_hg_cdf_inverse(float g, float r);
+uint32_t oracle_alias_sample(const spt_alias_table* a, float rand, float* prob);
+void oracle_env_lookup(const spt_scene_desc* d, const float wi[3], float rgb[3], float* pdf);
+void oracle_camera_ray(const spt_camera* cam, float x, float y, float o[3], float dir[3]);
+void oracle_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out);
+void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
+uint64_t oracle_rng_state(uint64_t seed, uint32_t pixel, uint32_t sample);
+void oracle_r2_offsets(uint32_t pixel, uint32_t spp, uint32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,494 @@
+// Wavefront path-tracing kernels for gfx950 (wave64).
+//
+// Replaces the three nested loops of PathTracer::render / trace_ray
+// (reference src/renderer/pt.rs:237-296 and 39-210) by a streaming pipeline over
+// SoA queues in HBM, one stage per kernel, one queue generation per bounce:
+//
+//   primary : camera sample -> ray -> closest hit, fused (pt.rs:265-276 + first
+//             `aggregate().intersect`).  One lane per pixel looping over the
+//             samples of this pass; only HITS are written out, compacted.
+//   shade   : one path vertex (pt.rs:56-96 medium, 112-193 surface, 195-206 RR):
+//             emission + MIS weight, Bxdf::sample, light sample -> shadow queue,
+//             continuation ray -> extension queue.
+//   shadow  : aggregate().intersect_test for the shadow queue; visible
+//             contributions are added to the sample's radiance slot.
+//   extend  : closest hit for the extension queue; misses take the environment
+//             term (pt.rs:97-111) and die, hits go to the next bounce's queue.
+//   resolve : per-pixel sum of the pass's sample slots, in sample order
+//             (Film::filter_pixel for the box filter, film.rs:71-91).
+//
+// Live-path compaction: every push uses __ballot / __popcll over the 64-lane wave
+// and ONE atomicAdd per wave on the queue counter, so queues stay dense and the
+// next stage runs with full waves.  Queue records are float4 / uint2 planes so each
+// lane's access is a 16-byte (or 8-byte) coalesced load/store.
+// All kernels are persistent-style: a fixed grid strides over a queue whose length
+// is read from device memory (the host never waits for counts between stages).
+//
+// Determinism: a camera sample owns a radiance slot; its contributions are added
+// in path order by exactly one lane at a time (stages are stream-ordered), and
+// pixels are summed in sample order, so the film is bit-reproducible and identical
+// for any shard layout / GPU count.
+#pragma once
+#include "shading.h"
+
+struct DCamera {
+    f3 eye, forward, up, right;
+    float half_cot;
+};
+
+struct PathQueue {            // SoA path-state queue (72 B / entry)
+    float4* o_tmin;           // origin, t_min
+    float4* d_pdf;            // direction, last_sample_pdf
+    float4* thr_slot;         // throughput, radiance-slot index (bits)
+    float4* lsi_meta;         // light_sampler_inputs.position, depth | (medium+1)<<8 (bits)
+    uint2* rng;               // PCG32 state
+};
+struct HitQueue {             // closest-hit records aligned with a PathQueue (20 B / entry)
+    float4* t_v_w_prim;       // t, v, w, prim (bits)
+    int32_t* inst;
+};
+struct ShadowQueue {          // 48 B / entry
+    float4* o_tmin;
+    float4* d_tmax;
+    float4* contrib_slot;
+};
+
+struct RenderCtx {
+    DCamera cam;
+    uint32_t width, height, spp, max_depth, sampler, division_x, division_y;
+    uint64_t seed;
+    uint32_t shard_index, shard_count, strip_rows;
+    uint32_t n_pixels;        // pixels of this shard
+    uint32_t pass_first;      // first sample index of this pass
+    uint32_t pass_samples;    // samples per pixel in this pass
+    PathQueue qa, qb;         // qa: paths with a hit record (input of shade); qb: paths to extend
+    HitQueue hits;
+    ShadowQueue shadow;
+    uint32_t* counts;         // [bounce][4] = {hit-queue length, shadow length, ext length, -}
+    float* rad;               // 3 planes [c][s][pixel] of per-sample radiance
+    float* film;              // n_pixels * 3 running sums
+    uint32_t* first_slot;     // per pixel: first sample of the pass that uses a rad slot
+    float aspect, width_inv, height_inv, spp_inv;
+};
+
+SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Wave-aggregated append: returns this lane's slot (valid only where pred).
+SPT_DEV uint32_t wave_push(bool pred, uint32_t* counter) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    unsigned long long lt = (lane == 0u) ? 0ull : (~0ull >> (64u - lane));
+    return base + (uint32_t)__popcll(mask & lt);
+}
+
+// PerspectiveCamera::generate_ray (camera/perspective.rs:40-47)
+SPT_DEV DRay camera_ray(const DCamera& c, float x, float y) {
+    DRay r;
+    r.o = c.eye;
+    r.d = normalize((c.forward * c.half_cot + c.right * x) + c.up * y);
+    r.t_min = kTMinEps;
+    return r;
+}
+
+// pixel sampler (pixel_sampler/{random,jittered,recurrence}.rs)
+SPT_DEV void pixel_offset(const RenderCtx& rc, uint32_t pixel, uint32_t s, DRng& rng, float* ox, float* oy) {
+    if (rc.sampler == SPT_SAMPLER_RECURRENCE) {
+        spt_r2_offset(pixel, rc.spp, s, ox, oy);
+    } else if (rc.sampler == SPT_SAMPLER_JITTERED) {
+        uint32_t ix = s % rc.division_x, iy = s / rc.division_x;
+        float inv_x = 1.0f / (float)rc.division_x, inv_y = 1.0f / (float)rc.division_y;
+        *ox = ((float)ix + rng.next()) * inv_x;
+        *oy = ((float)iy + rng.next()) * inv_y;
+    } else {
+        *ox = rng.next();
+        *oy = rng.next();
+    }
+}
+
+SPT_DEV uint32_t pack_meta(uint32_t depth, int32_t medium) { return depth | ((uint32_t)(medium + 1) << 8); }
+
+SPT_DEV void store_path(const PathQueue& q, uint32_t i, const DRay& ray, float last_pdf, f3 thr, uint32_t slot, f3 lsi,
+                        uint32_t meta, const DRng& rng) {
+    q.o_tmin[i] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.t_min);
+    q.d_pdf[i] = make_float4(ray.d.x, ray.d.y, ray.d.z, last_pdf);
+    q.thr_slot[i] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(slot));
+    q.lsi_meta[i] = make_float4(lsi.x, lsi.y, lsi.z, __uint_as_float(meta));
+    q.rng[i] = make_uint2((uint32_t)rng.s.state, (uint32_t)(rng.s.state >> 32));
+}
+
+// ---------------------------------------------------------------------------- primary
+__global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = lp < rc.n_pixels;
+    const uint32_t lpc = valid ? lp : 0u;
+    const uint32_t row_local = lpc / rc.width, i = lpc - row_local * rc.width;
+    const uint32_t strip = row_local / rc.strip_rows;
+    const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
+    const uint32_t pixel = j * rc.width + i;
+    const bool has_env = sc.env_w != 0u;
+    f3 sum = mk3(0, 0, 0);
+    if (valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+    uint32_t first = rc.pass_samples;
+    const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    for (uint32_t s = 0; s < rc.pass_samples; ++s) {
+        const uint32_t gs = rc.pass_first + s;
+        DRng rng;
+        rng.s = spt_rng_seed(rc.seed, pixel, gs);
+        float ox, oy;
+        pixel_offset(rc, pixel, gs, rng, &ox, &oy);
+        float x = (((float)i + ox) * rc.width_inv - 0.5f) * rc.aspect;           // pt.rs:269
+        float y = ((float)(rc.height - j - 1u) + oy) * rc.height_inv - 0.5f;       // pt.rs:270-271
+        DRay ray = camera_ray(rc.cam, x, y);
+        DHit h;
+        h.inst = -1;
+        if (valid) h = trace_closest(sc, ray, SPT_F32_MAX);
+        const bool hit = valid && h.inst >= 0;
+        const size_t ri = (size_t)s * rc.n_pixels + lp;
+        if (valid && !hit) {
+            if (has_env) {  // pt.rs:98-110 at depth 0: weight 1
+                f3 env;
+                float env_pdf;
+                env_strength_pdf(sc, ray.d, &env, &env_pdf);
+                f3 c = mk3(0, 0, 0) + (gray(1.0f) * env) * 1.0f;
+                if (first == rc.pass_samples) {
+                    sum = sum + c;
+                } else {
+                    rc.rad[ri] = c.x; rc.rad[plane + ri] = c.y; rc.rad[2 * plane + ri] = c.z;
+                }
+            } else if (first != rc.pass_samples) {
+                rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
+            }
+        }
+        if (hit) {
+            if (first == rc.pass_samples) first = s;
+            rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
+        }
+        uint32_t slot = wave_push(hit, &rc.counts[0]);
+        if (hit) {
+            store_path(rc.qa, slot, ray, 0.0f, gray(1.0f), (uint32_t)ri, mk3(0, 0, 0), pack_meta(0u, -1), rng);
+            rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
+            rc.hits.inst[slot] = h.inst;
+        }
+    }
+    if (valid) {
+        rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
+        rc.first_slot[lp] = first;
+    }
+}
+
+SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
+    const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    rc.rad[slot] = rc.rad[slot] + c.x;
+    rc.rad[plane + slot] = rc.rad[plane + slot] + c.y;
+    rc.rad[2 * plane + slot] = rc.rad[2 * plane + slot] + c.z;
+}
+
+// ---------------------------------------------------------------------------- shade
+// One iteration of the `while curr_depth < max_depth` loop of trace_ray, minus the
+// two traversals, for the path vertex in qa[idx] / hits[idx].
+__global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+    const uint32_t n = rc.counts[4 * bounce + 0];
+    uint32_t* shadow_count = &rc.counts[4 * bounce + 1];
+    uint32_t* ext_count = &rc.counts[4 * bounce + 2];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const uint32_t idx = i0 + lane_id();
+        const bool active = idx < n;
+        bool want_shadow = false, want_ext = false;
+        DRay shadow_ray, next_ray;
+        float shadow_tmax = 0.0f, next_pdf = 0.0f;
+        f3 contrib = mk3(0, 0, 0), thr = gray(1.0f), lsi = mk3(0, 0, 0);
+        uint32_t slot = 0u, depth = 0u;
+        int32_t medium = -1;
+        DRng rng;
+        rng.s.state = 0ull;
+        if (active) {
+            float4 a = rc.qa.o_tmin[idx], b = rc.qa.d_pdf[idx], c = rc.qa.thr_slot[idx], d = rc.qa.lsi_meta[idx];
+            uint2 rs = rc.qa.rng[idx];
+            float4 hv = rc.hits.t_v_w_prim[idx];
+            DRay ray;
+            ray.o = mk3(a); ray.t_min = a.w;
+            ray.d = mk3(b);
+            float last_pdf = b.w;
+            thr = mk3(c);
+            slot = __float_as_uint(c.w);
+            lsi = mk3(d);
+            uint32_t meta = __float_as_uint(d.w);
+            depth = meta & 0xffu;
+            medium = (int32_t)(meta >> 8) - 1;
+            rng.s.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+            DHit h;
+            h.t = hv.x; h.v = hv.y; h.w = hv.z; h.prim = __float_as_int(hv.w);
+            h.inst = rc.hits.inst[idx];
+            const bool does_hit = h.inst >= 0;
+            bool alive = true;       // false: path ended without the RR / depth tail (`break`)
+            bool scattered = false;  // a new ray was produced (tail applies)
+
+            DInstance in;
+            DInter it;
+            if (does_hit) {
+                in = load_instance(sc, (uint32_t)h.inst);
+                it = reconstruct_hit(sc, in, ray, h);
+            }
+
+            if (medium >= 0) {  // pt.rs:56-96
+                const spt_medium& md = sc.mediums[medium];
+                f3 sigma_t = mk3(md.sigma_t);
+                f3 wo = -ray.d;
+                float rx = rng.next(), ry = rng.next();  // Homogeneous::sample_pi, homogeneous.rs:30-58
+                float sample_sigma_t = (rx < 1.0f / 3.0f) ? md.sigma_t[0] : ((rx < 2.0f / 3.0f) ? md.sigma_t[1] : md.sigma_t[2]);
+                float sample_t = -spt_log(1.0f - ry) / sample_sigma_t;
+                float tt = spt_min(sample_t, h.t);
+                f3 attenuation = cexp((-sigma_t) * tt);
+                f3 pi = ray.o - wo * tt;
+                if (sample_t < h.t) {
+                    float atten_pdf = cavg(sigma_t * attenuation);
+                    thr = thr * crcp(attenuation * mk3(md.sigma_s), atten_pdf);
+                    // still in the medium: in-scattering from one light sample
+                    lsi = pi;
+                    DLightSample ls;
+                    if (sample_light(sc, lsi, rng, &ls)) {
+                        float phase = henyey_greenstein(md.g, dot(wo, ls.dir));
+                        // shadow_ray_from_medium (pt.rs:212-233): probe the last-hit basic primitive
+                        // with the world-space ray, in its own object space
+                        DRay sr;
+                        sr.o = pi; sr.d = ls.dir; sr.t_min = kTMinEps;
+                        float probe_max = ls.dist - 0.001f;
+                        float transported = ls.dist;
+                        bool probe_hit = false;
+                        float probe_t = 0.0f;
+                        if (does_hit && in.prim_type == SPT_PRIM_MESH) {
+                            float t, v, w;
+                            if (tri_test(sc.tri_pos, (uint32_t)h.prim, sr, &t, &v, &w) && t > sr.t_min && t < probe_max) { probe_hit = true; probe_t = t; }
+                        } else if (does_hit) {
+                            float mn, mx;
+                            if (sphere_roots(sc.spheres[in.prim_id], sr, &mn, &mx)) {
+                                float t = (mn < sr.t_min) ? mx : mn;
+                                if (sr.t_min < t && t < probe_max) { probe_hit = true; probe_t = t; }
+                            }
+                        }
+                        if (probe_hit) { transported = probe_t; sr.t_min += probe_t; }
+                        else { sr.t_min += ls.dist - 0.001f; }
+                        f3 atten = cexp((-sigma_t) * transported);
+                        if (ls.pdf != 0.0f && spt_is_finite(ls.pdf)) {
+                            f3 li;
+                            if (ls.is_delta) {
+                                li = crcp((atten * phase) * ls.strength, ls.pdf);
+                            } else {
+                                float weight = power_heuristic(ls.pdf, phase);
+                                li = crcp(((atten * phase) * ls.strength) * weight, ls.pdf);
+                            }
+                            contrib = thr * li;
+                            shadow_ray = sr;
+                            shadow_tmax = ls.dist - 0.001f;
+                            want_shadow = true;
+                        }
+                    }
+                    // Homogeneous::sample_wi (homogeneous.rs:60-70)
+                    float r0 = rng.next(), r1 = rng.next();
+                    float cos_theta = hg_cdf_inverse(md.g, r0);
+                    float sin_theta = spt_sqrt(1.0f - cos_theta * cos_theta);
+                    float phi = 2.0f * SPT_PI * r1;
+                    float sp, cp;
+                    spt_sincos(phi, &sp, &cp);
+                    f3 wi = hg_local_to_world(wo, mk3(sin_theta * cp, sin_theta * sp, cos_theta));
+                    next_pdf = henyey_greenstein(md.g, cos_theta);
+                    next_ray.o = pi; next_ray.d = wi; next_ray.t_min = kTMinEps;
+                    scattered = true;
+                } else {
+                    // left the medium: `continue` (pt.rs:62-64) re-traces the SAME ray with no medium and
+                    // without RR / depth change; the recorded hit is that re-trace's result.
+                    float atten_pdf = cavg(attenuation);
+                    thr = thr * crcp(attenuation, atten_pdf);
+                    medium = -1;
+                }
+            }
+
+            if (!scattered && medium < 0) {
+                if (!does_hit) {  // pt.rs:97-111 (only reached here after leaving a medium)
+                    if (sc.env_w != 0u) {
+                        f3 env;
+                        float env_pdf;
+                        env_strength_pdf(sc, ray.d, &env, &env_pdf);
+                        float weight = 1.0f;
+                        if (depth != 0u) weight = power_heuristic(last_pdf, pdf_env_light(sc) * env_pdf);
+                        rad_add(rc, slot, (thr * env) * weight);
+                    }
+                    alive = false;
+                } else {  // pt.rs:112-193
+                    const spt_surface& sf = sc.surfaces[it.surface];
+                    const uint32_t sflags = sf.flags;
+                    DMat mt = load_material(sc, sf.material);
+                    DCoord coord = surface_coord(sflags, ray, it);
+                    f3 po = it.position;
+                    f3 le = mk3(sf.emissive);
+                    if (luminance(le) > 0.0f) {
+                        float weight = 1.0f;
+                        if (depth != 0u) weight = power_heuristic(last_pdf, pdf_shape_light(sc, in, sflags, lsi, it, h.prim));
+                        rad_add(rc, slot, (thr * le) * weight);
+                    }
+                    f3 wo = coord.to_local(-ray.d);
+                    DBxdfSample samp = mat_sample(mt, wo, rng);
+                    lsi = po;
+                    if (!mat_is_delta(mt)) {
+                        DLightSample ls;
+                        if (sample_light(sc, lsi, rng, &ls)) {
+                            f3 wi = coord.to_local(ls.dir);
+                            f3 f = mat_eval(mt, wo, wi);
+                            float mpdf = mat_pdf(mt, wo, wi);
+                            if (ls.pdf != 0.0f && spt_is_finite(ls.pdf)) {
+                                f3 li;
+                                if (ls.is_delta) {
+                                    li = crcp((ls.strength * f) * spt_abs(wi.z), spt_max(ls.pdf, 0.00001f));
+                                } else {
+                                    float weight = power_heuristic(ls.pdf, mpdf);
+                                    li = crcp(((ls.strength * f) * spt_abs(wi.z)) * weight, spt_max(ls.pdf, 0.00001f));
+                                }
+                                contrib = thr * li;
+                                shadow_ray.o = po; shadow_ray.d = ls.dir;
+                                shadow_ray.t_min = kTMinEps / spt_max(spt_abs(wi.z), 0.00001f);
+                                shadow_tmax = ls.dist - 0.001f;
+                                want_shadow = true;
+                            }
+                        }
+                    }
+                    next_pdf = samp.pdf;
+                    f3 wi_world = coord.to_world(samp.wi);
+                    next_ray.o = po; next_ray.d = wi_world;
+                    next_ray.t_min = kTMinEps / spt_max(spt_abs(samp.wi.z), 0.00001f);
+                    thr = thr * crcp(samp.f * spt_abs(samp.wi.z), spt_max(samp.pdf, 0.00001f));
+                    float hd = dot(wi_world, coord.hemi);  // Coordinate::in_expected_hemisphere
+                    if (!(samp.transmit ? (hd <= 0.0f) : (hd >= 0.0f))) alive = false;
+                    if (alive && dot(wi_world, it.normal) < 0.0f)
+                        medium = (sflags & SPT_SURF_DOUBLE_SIDED) ? -1 : sf.inside_medium;  // Surface::inside_medium
+                    scattered = true;
+                }
+            }
+
+            // a zero contribution needs no visibility test (the reference adds 0)
+            if (want_shadow && contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f) want_shadow = false;
+
+            if (alive && scattered) {  // pt.rs:195-206
+                if (all_finite(thr)) {
+                    float rr_rand = rng.next();
+                    float rr_prop = spt_clamp(luminance(thr), 0.001f, 0.95f);
+                    if (!(rr_rand > rr_prop)) {
+                        thr = thr * (1.0f / rr_prop);
+                        depth += 1u;
+                        want_ext = depth < rc.max_depth;
+                    }
+                }
+            }
+        }
+        uint32_t ss = wave_push(want_shadow, shadow_count);
+        if (want_shadow) {
+            rc.shadow.o_tmin[ss] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.t_min);
+            rc.shadow.d_tmax[ss] = make_float4(shadow_ray.d.x, shadow_ray.d.y, shadow_ray.d.z, shadow_tmax);
+            rc.shadow.contrib_slot[ss] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+        }
+        uint32_t es = wave_push(want_ext, ext_count);
+        if (want_ext) store_path(rc.qb, es, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
+    }
+}
+
+// ---------------------------------------------------------------------------- shadow
+__global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
+    const uint32_t n = rc.counts[4 * bounce + 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx], c = rc.shadow.contrib_slot[idx];
+        DRay r;
+        r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+        if (!trace_any(sc, r, b.w)) rad_add(rc, __float_as_uint(c.w), mk3(c));
+    }
+}
+
+// ---------------------------------------------------------------------------- extend
+__global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
+    const uint32_t n = rc.counts[4 * bounce + 2];
+    uint32_t* next_count = &rc.counts[4 * (bounce + 1) + 0];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const uint32_t idx = i0 + lane_id();
+        const bool active = idx < n;
+        bool keep = false;
+        float4 a, b, c, d;
+        uint2 rs;
+        DHit h;
+        h.inst = -1; h.t = SPT_F32_MAX; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
+        if (active) {
+            a = rc.qb.o_tmin[idx]; b = rc.qb.d_pdf[idx]; c = rc.qb.thr_slot[idx]; d = rc.qb.lsi_meta[idx];
+            rs = rc.qb.rng[idx];
+            DRay r;
+            r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+            h = trace_closest(sc, r, SPT_F32_MAX);
+            const uint32_t meta = __float_as_uint(d.w);
+            const bool in_medium = (meta >> 8) != 0u;
+            if (h.inst >= 0 || in_medium) {
+                keep = true;
+            } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
+                f3 env;
+                float env_pdf;
+                env_strength_pdf(sc, r.d, &env, &env_pdf);
+                float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
+                rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
+            }
+        }
+        uint32_t slot = wave_push(keep, next_count);
+        if (keep) {
+            rc.qa.o_tmin[slot] = a; rc.qa.d_pdf[slot] = b; rc.qa.thr_slot[slot] = c; rc.qa.lsi_meta[slot] = d;
+            rc.qa.rng[slot] = rs;
+            rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
+            rc.hits.inst[slot] = h.inst;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- resolve
+__global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= rc.n_pixels) return;
+    const uint32_t first = rc.first_slot[lp];
+    if (first >= rc.pass_samples) return;
+    const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+    for (uint32_t s = first; s < rc.pass_samples; ++s) {
+        const size_t ri = (size_t)s * rc.n_pixels + lp;
+        sum = sum + mk3(rc.rad[ri], rc.rad[plane + ri], rc.rad[2 * plane + ri]);  // film.rs:87
+    }
+    rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
+}
+
+// film.rs:91: color / weight_sum  (Color / f32 = Color * (1/f32))
+__global__ void __launch_bounds__(256) k_finish(RenderCtx rc, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rc.n_pixels * 3u) return;
+    out[i] = rc.film[i] * rc.spp_inv;
+}
+
+// ---------------------------------------------------------------------------- test seams
+__global__ void __launch_bounds__(256) k_trace_closest(DScene sc, uint32_t n, const spt_ray* rays, spt_hit* hits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DRay r;
+    r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
+    DHit h = trace_closest(sc, r, rays[i].t_max);
+    const bool hit = h.inst >= 0;
+    hits[i].t = hit ? h.t : SPT_F32_MAX;
+    hits[i].instance = h.inst;
+    hits[i].prim = hit ? h.prim : -1;
+    hits[i].v = hit ? h.v : 0.0f;
+    hits[i].w = hit ? h.w : 0.0f;
+}
+__global__ void __launch_bounds__(256) k_trace_any(DScene sc, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DRay r;
+    r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
+    occluded[i] = trace_any(sc, r, rays[i].t_max) ? 1 : 0;
+}

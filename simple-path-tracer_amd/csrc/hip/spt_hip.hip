@@ -1,0 +1,520 @@
+// libspt_hip.so — C ABI (include/spt_abi.h) over the gfx950 kernels.
+// Host code here only validates descriptors, moves the flattened scene into HBM
+// and enqueues kernels on one HIP stream; there is no CPU rendering path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+struct AbiError {
+    spt_status code;
+    std::string msg;
+};
+[[noreturn]] void fail(spt_status code, const std::string& msg) { throw AbiError{code, msg}; }
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            fail(e_ == hipErrorOutOfMemory ? SPT_ERR_OUT_OF_MEMORY : SPT_ERR_HIP,                    \
+                 std::string(#expr) + ": " + hipGetErrorString(e_));                                 \
+    } while (0)
+
+int usable_device_count() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void ensure(size_t n) {
+        if (n > bytes) alloc(n);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    void upload(const T* src, size_t count) {
+        alloc(std::max<size_t>(count * sizeof(T), 16));
+        if (count) HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+uint32_t bvh_depth(const spt_bvh_node* nodes, uint32_t n_nodes, uint32_t root, uint32_t n_items, const char* what) {
+    // iterative DFS; also validates indices so the kernels never read out of bounds
+    if (n_nodes == 0) return 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st;
+    st.emplace_back(root, 1u);
+    uint32_t depth = 0, visited = 0;
+    while (!st.empty()) {
+        auto [ni, d] = st.back();
+        st.pop_back();
+        if (ni >= n_nodes) fail(SPT_ERR_INVALID_ARG, std::string(what) + ": node index out of range");
+        if (++visited > n_nodes) fail(SPT_ERR_INVALID_ARG, std::string(what) + ": node graph is not a tree");
+        depth = std::max(depth, d);
+        const spt_bvh_node& nd = nodes[ni];
+        if (nd.b & SPT_LEAF_FLAG) {
+            uint32_t cnt = nd.b & ~SPT_LEAF_FLAG;
+            if ((uint64_t)nd.a + cnt > n_items) fail(SPT_ERR_INVALID_ARG, std::string(what) + ": leaf item range out of bounds");
+        } else {
+            st.emplace_back(nd.a, d + 1);
+            st.emplace_back(nd.b, d + 1);
+        }
+    }
+    return depth;
+}
+
+}  // namespace
+
+struct spt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DScene d{};
+    DeviceBuffer tlas, blas, tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
+    DeviceBuffer light_props, light_u, light_k, env_texels, env_props, env_u, env_k;
+    // render workspace (grown on demand, reused between calls)
+    DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, sh[3], counts, rad, film, first_slot, out;
+    DeviceBuffer trace_in, trace_out;
+    std::mutex mu;
+    uint32_t max_depth_alloc = 0;
+    std::vector<hipEvent_t> events;
+    ~spt_scene() {
+        (void)hipSetDevice(device);
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+void validate(const spt_scene_desc& s) {
+    if (s.abi_version != SPT_ABI_VERSION) fail(SPT_ERR_INVALID_ARG, "scene desc: abi_version mismatch");
+    if (s.aggregate > SPT_AGGREGATE_BVH) fail(SPT_ERR_INVALID_ARG, "scene desc: bad aggregate");
+    auto need = [](const void* p, uint32_t n, const char* what) {
+        if (n && !p) fail(SPT_ERR_INVALID_ARG, std::string("scene desc: null array '") + what + "'");
+    };
+    need(s.tlas_nodes, s.n_tlas_nodes, "tlas_nodes");
+    need(s.instances, s.n_instances, "instances");
+    need(s.meshes, s.n_meshes, "meshes");
+    need(s.blas_nodes, s.n_blas_nodes, "blas_nodes");
+    need(s.tri_pos, s.n_tris, "tri_pos");
+    need(s.tri_attr, s.n_tris, "tri_attr");
+    need(s.spheres, s.n_spheres, "spheres");
+    need(s.surfaces, s.n_surfaces, "surfaces");
+    need(s.materials, s.n_materials, "materials");
+    need(s.mediums, s.n_mediums, "mediums");
+    need(s.lights, s.n_lights, "lights");
+    if (s.n_instances && s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes == 0)
+        fail(SPT_ERR_INVALID_ARG, "scene desc: bvh aggregate without TLAS nodes");
+    for (uint32_t i = 0; i < s.n_instances; ++i) {
+        const spt_instance& in = s.instances[i];
+        if (in.prim_type == SPT_PRIM_SPHERE) {
+            if (in.prim_id >= s.n_spheres) fail(SPT_ERR_INVALID_ARG, "scene desc: instance sphere index out of range");
+        } else if (in.prim_type == SPT_PRIM_MESH) {
+            if (in.prim_id >= s.n_meshes) fail(SPT_ERR_INVALID_ARG, "scene desc: instance mesh index out of range");
+        } else {
+            fail(SPT_ERR_INVALID_ARG, "scene desc: bad instance prim_type");
+        }
+        if (in.surface >= s.n_surfaces) fail(SPT_ERR_INVALID_ARG, "scene desc: instance surface index out of range");
+        if (in.light >= (int32_t)s.n_lights) fail(SPT_ERR_INVALID_ARG, "scene desc: instance light index out of range");
+    }
+    for (uint32_t i = 0; i < s.n_meshes; ++i) {
+        const spt_mesh& m = s.meshes[i];
+        if (m.root >= s.n_blas_nodes || (uint64_t)m.tri_first + m.tri_count > s.n_tris || m.tri_count == 0)
+            fail(SPT_ERR_INVALID_ARG, "scene desc: mesh ranges out of bounds");
+    }
+    for (uint32_t i = 0; i < s.n_surfaces; ++i) {
+        if (s.surfaces[i].material >= s.n_materials) fail(SPT_ERR_INVALID_ARG, "scene desc: surface material out of range");
+        if (s.surfaces[i].inside_medium >= (int32_t)s.n_mediums) fail(SPT_ERR_INVALID_ARG, "scene desc: surface medium out of range");
+        if (s.surfaces[i].inside_medium >= 254) fail(SPT_ERR_UNSUPPORTED, "scene desc: more than 254 mediums");
+    }
+    for (uint32_t i = 0; i < s.n_materials; ++i)
+        if (s.materials[i].bxdf > SPT_BXDF_PSEUDO) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown bxdf tag");
+    for (uint32_t i = 0; i < s.n_lights; ++i) {
+        const spt_light& l = s.lights[i];
+        if (l.type > SPT_LIGHT_ENV) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown light type");
+        if (l.type == SPT_LIGHT_SHAPE && l.instance >= s.n_instances) fail(SPT_ERR_INVALID_ARG, "scene desc: shape light instance out of range");
+        if (l.type == SPT_LIGHT_ENV && (s.env.width == 0 || s.env.height == 0)) fail(SPT_ERR_INVALID_ARG, "scene desc: env light without env map");
+    }
+    if (s.env_light_index >= (int32_t)s.n_lights) fail(SPT_ERR_INVALID_ARG, "scene desc: env_light_index out of range");
+    if (s.light_sampler > SPT_LIGHT_SAMPLER_POWER_IS) fail(SPT_ERR_INVALID_ARG, "scene desc: bad light_sampler");
+    if (s.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS && s.n_lights) {
+        if (s.light_alias.n != s.n_lights || !s.light_alias.props || !s.light_alias.u || !s.light_alias.k)
+            fail(SPT_ERR_INVALID_ARG, "scene desc: power_is sampler needs an alias table over the lights");
+        for (uint32_t i = 0; i < s.n_lights; ++i)
+            if (s.light_alias.k[i] >= s.n_lights) fail(SPT_ERR_INVALID_ARG, "scene desc: light alias index out of range");
+    }
+    if (s.env.width || s.env.height) {
+        uint64_t n = (uint64_t)s.env.width * s.env.height;
+        if (n == 0 || n > 0x7fffffffull) fail(SPT_ERR_INVALID_ARG, "scene desc: bad env size");
+        if (!s.env.texels || !s.env.alias.props || !s.env.alias.u || !s.env.alias.k || s.env.alias.n != n)
+            fail(SPT_ERR_INVALID_ARG, "scene desc: env map needs texels and an alias table");
+        for (uint64_t i = 0; i < n; ++i)
+            if (s.env.alias.k[i] >= n) fail(SPT_ERR_INVALID_ARG, "scene desc: env alias index out of range");
+    }
+}
+
+uint32_t shard_row_count(const spt_render_params& p) {
+    uint32_t sc = p.shard_count ? p.shard_count : 1u, sr = p.strip_rows ? p.strip_rows : 1u;
+    uint32_t rows = 0;
+    for (uint32_t j = 0; j < p.height; ++j)
+        if ((j / sr) % sc == p.shard_index) ++rows;
+    return rows;
+}
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kPersistentBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
+
+}  // namespace
+
+extern "C" {
+
+const char* spt_last_error(void) { return g_error.c_str(); }
+uint32_t spt_abi_version(void) { return SPT_ABI_VERSION; }
+
+spt_status spt_device_count(int32_t* count) {
+    if (!count) { g_error = "device_count: null argument"; return SPT_ERR_INVALID_ARG; }
+    *count = usable_device_count();
+    return SPT_OK;
+}
+
+spt_status spt_shard_rows(const spt_render_params* params, uint32_t* rows) {
+    if (!params || !rows) { g_error = "shard_rows: null argument"; return SPT_ERR_INVALID_ARG; }
+    *rows = shard_row_count(*params);
+    return SPT_OK;
+}
+
+spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scene** out) {
+    if (!desc || !out) { g_error = "scene_create: null argument"; return SPT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    spt_scene* sc = nullptr;
+    try {
+        validate(*desc);
+        int n = usable_device_count();
+        if (n <= 0) fail(SPT_ERR_NO_DEVICE, "no HIP device is visible: libspt_hip has no CPU fallback");
+        if (device < 0 || device >= n) fail(SPT_ERR_NO_DEVICE, "device index out of range");
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            fail(SPT_ERR_NO_DEVICE, std::string("device is '") + prop.gcnArchName + "', the kernels are built for gfx950 only");
+        HIP_CHECK(hipSetDevice(device));
+        sc = new spt_scene();
+        sc->device = device;
+        HIP_CHECK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+        const spt_scene_desc& s = *desc;
+        // stack need: reference-order traversal holds at most depth+1 entries per level of nesting
+        uint32_t tlas_depth = 0, blas_depth = 0;
+        if (s.aggregate == SPT_AGGREGATE_BVH) tlas_depth = bvh_depth(s.tlas_nodes, s.n_tlas_nodes, 0, s.n_instances, "tlas");
+        for (uint32_t i = 0; i < s.n_meshes; ++i) {
+            // each BLAS must index triangles inside its own mesh range
+            blas_depth = std::max(blas_depth, bvh_depth(s.blas_nodes, s.n_blas_nodes, s.meshes[i].root, s.n_tris, "blas"));
+        }
+        uint32_t cap = tlas_depth + blas_depth + 4;
+        if (cap * kBlock * 4u > 160u * 1024u) fail(SPT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
+        sc->tlas.upload(s.tlas_nodes, s.n_tlas_nodes);
+        sc->blas.upload(s.blas_nodes, s.n_blas_nodes);
+        sc->tri_pos.upload(s.tri_pos, s.n_tris);
+        sc->tri_attr.upload(s.tri_attr, s.n_tris);
+        sc->instances.upload(s.instances, s.n_instances);
+        sc->meshes.upload(s.meshes, s.n_meshes);
+        sc->spheres.upload(s.spheres, s.n_spheres);
+        sc->surfaces.upload(s.surfaces, s.n_surfaces);
+        sc->materials.upload(s.materials, s.n_materials);
+        sc->mediums.upload(s.mediums, s.n_mediums);
+        sc->lights.upload(s.lights, s.n_lights);
+        const bool pis = s.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS;
+        sc->light_props.upload(s.light_alias.props, pis ? s.n_lights : 0);
+        sc->light_u.upload(s.light_alias.u, pis ? s.n_lights : 0);
+        sc->light_k.upload(s.light_alias.k, pis ? s.n_lights : 0);
+        size_t ne = (size_t)s.env.width * s.env.height;
+        sc->env_texels.upload(s.env.texels, ne * 3);
+        sc->env_props.upload(s.env.alias.props, ne);
+        sc->env_u.upload(s.env.alias.u, ne);
+        sc->env_k.upload(s.env.alias.k, ne);
+        DScene& d = sc->d;
+        d.tlas_nodes = sc->tlas.as<float4>();
+        d.blas_nodes = sc->blas.as<float4>();
+        d.tri_pos = sc->tri_pos.as<float4>();
+        d.tri_attr = sc->tri_attr.as<float4>();
+        d.instances = sc->instances.as<float4>();
+        d.meshes = sc->meshes.as<uint4>();
+        d.spheres = sc->spheres.as<float4>();
+        d.surfaces = sc->surfaces.as<spt_surface>();
+        d.materials = sc->materials.as<spt_material>();
+        d.mediums = sc->mediums.as<spt_medium>();
+        d.lights = sc->lights.as<spt_light>();
+        d.light_props = sc->light_props.as<float>();
+        d.light_u = sc->light_u.as<float>();
+        d.light_k = sc->light_k.as<uint32_t>();
+        d.env_texels = sc->env_texels.as<float>();
+        d.env_props = sc->env_props.as<float>();
+        d.env_u = sc->env_u.as<float>();
+        d.env_k = sc->env_k.as<uint32_t>();
+        d.n_tlas_nodes = s.n_tlas_nodes;
+        d.n_instances = s.n_instances;
+        d.n_lights = s.n_lights;
+        d.n_meshes = s.n_meshes;
+        d.aggregate = s.aggregate;
+        d.light_sampler = s.light_sampler;
+        d.env_light_index = s.env_light_index;
+        d.env_w = s.env.width;
+        d.env_h = s.env.height;
+        for (int i = 0; i < 3; ++i) d.env_scale[i] = s.env.scale[i];
+        d.stack_cap = cap;
+        *out = sc;
+        return SPT_OK;
+    } catch (const AbiError& e) {
+        g_error = e.msg;
+        delete sc;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_error = std::string("scene_create: ") + e.what();
+        delete sc;
+        return SPT_ERR_OUT_OF_MEMORY;
+    }
+}
+
+void spt_scene_destroy(spt_scene* scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    (void)hipStreamSynchronize(scene->stream);
+    DeviceBuffer* all[] = {&scene->tlas, &scene->blas, &scene->tri_pos, &scene->tri_attr, &scene->instances, &scene->meshes,
+                           &scene->spheres, &scene->surfaces, &scene->materials, &scene->mediums, &scene->lights,
+                           &scene->light_props, &scene->light_u, &scene->light_k, &scene->env_texels, &scene->env_props,
+                           &scene->env_u, &scene->env_k, &scene->hit_f4, &scene->hit_inst, &scene->counts, &scene->rad,
+                           &scene->film, &scene->first_slot, &scene->out, &scene->trace_in, &scene->trace_out};
+    for (auto* b : all) b->release();
+    for (auto& b : scene->qa) b.release();
+    for (auto& b : scene->qb) b.release();
+    for (auto& b : scene->sh) b.release();
+    delete scene;
+}
+
+spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt_render_params* params,
+                      float* rgb_mean_out, spt_render_stats* stats) {
+    if (!scene_c || !cam || !params || !rgb_mean_out) { g_error = "render: null argument"; return SPT_ERR_INVALID_ARG; }
+    spt_scene* sc = const_cast<spt_scene*>(scene_c);
+    std::lock_guard<std::mutex> lock(sc->mu);
+    try {
+        const spt_render_params& p = *params;
+        if (p.width == 0 || p.height == 0 || p.spp == 0) fail(SPT_ERR_INVALID_ARG, "render: width, height and spp must be > 0");
+        if (p.max_depth > 255) fail(SPT_ERR_UNSUPPORTED, "render: max_depth > 255");
+        if (p.sampler > SPT_SAMPLER_RECURRENCE) fail(SPT_ERR_INVALID_ARG, "render: unknown sampler");
+        if (p.sampler == SPT_SAMPLER_JITTERED && (p.division_x == 0 || p.division_y == 0 || p.division_x * p.division_y != p.spp))
+            fail(SPT_ERR_INVALID_ARG, "render: jittered sampler needs spp == division_x * division_y");
+        const uint32_t shard_count = p.shard_count ? p.shard_count : 1u, strip_rows = p.strip_rows ? p.strip_rows : 1u;
+        if (p.shard_index >= shard_count) fail(SPT_ERR_INVALID_ARG, "render: shard_index >= shard_count");
+        if ((uint64_t)p.width * p.height > 0xffffffffull) fail(SPT_ERR_UNSUPPORTED, "render: more than 2^32 pixels");
+        const uint32_t rows = shard_row_count(p);
+        const uint64_t n_pix64 = (uint64_t)rows * p.width;
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        if (n_pix64 == 0) return SPT_OK;
+        if (n_pix64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: shard larger than 2^31 pixels");
+        const uint32_t n_pix = (uint32_t)n_pix64;
+        HIP_CHECK(hipSetDevice(sc->device));
+
+        // samples per pass: keep the queues around a few million entries
+        uint32_t spp_pass = p.samples_per_pass;
+        if (spp_pass == 0) {
+            const uint64_t target = 8ull << 20;
+            spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
+        }
+        spp_pass = std::min(spp_pass, p.spp);
+        const uint64_t cap64 = (uint64_t)n_pix * spp_pass;
+        if (cap64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: pass too large (lower samples_per_pass)");
+        const size_t cap = (size_t)cap64;
+
+        for (int k = 0; k < 4; ++k) { sc->qa[k].ensure(cap * 16); sc->qb[k].ensure(cap * 16); }
+        sc->qa[4].ensure(cap * 8);
+        sc->qb[4].ensure(cap * 8);
+        sc->hit_f4.ensure(cap * 16);
+        sc->hit_inst.ensure(cap * 4);
+        for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
+        const size_t counts_bytes = (size_t)(p.max_depth + 2) * 4 * sizeof(uint32_t);
+        sc->counts.ensure(counts_bytes);
+        sc->rad.ensure(cap * 3 * sizeof(float));
+        sc->film.ensure((size_t)n_pix * 3 * sizeof(float));
+        sc->first_slot.ensure((size_t)n_pix * sizeof(uint32_t));
+        sc->out.ensure((size_t)n_pix * 3 * sizeof(float));
+
+        RenderCtx rc{};
+        rc.cam.eye = f3{cam->eye[0], cam->eye[1], cam->eye[2]};
+        rc.cam.forward = f3{cam->forward[0], cam->forward[1], cam->forward[2]};
+        rc.cam.up = f3{cam->up[0], cam->up[1], cam->up[2]};
+        rc.cam.right = f3{cam->right[0], cam->right[1], cam->right[2]};
+        rc.cam.half_cot = cam->half_cot_half_fov;
+        rc.width = p.width; rc.height = p.height; rc.spp = p.spp; rc.max_depth = p.max_depth;
+        rc.sampler = p.sampler; rc.division_x = p.division_x; rc.division_y = p.division_y;
+        rc.seed = p.seed;
+        rc.shard_index = p.shard_index; rc.shard_count = shard_count; rc.strip_rows = strip_rows;
+        rc.n_pixels = n_pix;
+        rc.qa = PathQueue{sc->qa[0].as<float4>(), sc->qa[1].as<float4>(), sc->qa[2].as<float4>(), sc->qa[3].as<float4>(), sc->qa[4].as<uint2>()};
+        rc.qb = PathQueue{sc->qb[0].as<float4>(), sc->qb[1].as<float4>(), sc->qb[2].as<float4>(), sc->qb[3].as<float4>(), sc->qb[4].as<uint2>()};
+        rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
+        rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
+        rc.counts = sc->counts.as<uint32_t>();
+        rc.rad = sc->rad.as<float>();
+        rc.film = sc->film.as<float>();
+        rc.first_slot = sc->first_slot.as<uint32_t>();
+        rc.aspect = (float)p.width / (float)p.height;   // pt.rs:239
+        rc.width_inv = 1.0f / (float)p.width;           // pt.rs:250-251
+        rc.height_inv = 1.0f / (float)p.height;
+        rc.spp_inv = 1.0f / (float)p.spp;
+
+        hipStream_t st = sc->stream;
+        const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
+        const size_t lds = (size_t)sc->d.stack_cap * kBlock * sizeof(uint32_t);
+        const uint32_t pix_blocks = (n_pix + kBlock - 1) / kBlock;
+        struct Span { int cls; size_t e0; };
+        std::vector<Span> spans;
+        size_t ev_used = 0;
+        auto get_event = [&]() -> hipEvent_t {
+            if (ev_used == sc->events.size()) {
+                hipEvent_t e;
+                HIP_CHECK(hipEventCreate(&e));
+                sc->events.push_back(e);
+            }
+            return sc->events[ev_used++];
+        };
+        auto begin = [&](int cls) {
+            if (!profile) return;
+            spans.push_back(Span{cls, ev_used});
+            HIP_CHECK(hipEventRecord(get_event(), st));
+        };
+        auto end = [&]() {
+            if (!profile) return;
+            HIP_CHECK(hipEventRecord(get_event(), st));
+        };
+        hipEvent_t ev_total0 = get_event(), ev_total1 = get_event();
+        HIP_CHECK(hipEventRecord(ev_total0, st));
+        HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
+        std::vector<uint32_t> h_counts;
+        uint64_t seg_closest = 0, seg_shadow = 0;
+        for (uint32_t s0 = 0; s0 < p.spp; s0 += spp_pass) {
+            rc.pass_first = s0;
+            rc.pass_samples = std::min(spp_pass, p.spp - s0);
+            begin(SPT_K_OTHER);
+            HIP_CHECK(hipMemsetAsync(rc.counts, 0, counts_bytes, st));
+            end();
+            begin(SPT_K_PRIMARY);
+            hipLaunchKernelGGL(k_primary, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+            end();
+            for (uint32_t b = 0; b < p.max_depth; ++b) {
+                begin(SPT_K_SHADE);
+                hipLaunchKernelGGL(k_shade, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                end();
+                begin(SPT_K_SHADOW);
+                hipLaunchKernelGGL(k_shadow, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                end();
+                if (b + 1 < p.max_depth) {
+                    begin(SPT_K_EXTEND);
+                    hipLaunchKernelGGL(k_extend, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                    end();
+                }
+            }
+            begin(SPT_K_RESOLVE);
+            hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
+            end();
+            if (stats) {
+                h_counts.resize((size_t)(p.max_depth + 2) * 4);
+                HIP_CHECK(hipMemcpyAsync(h_counts.data(), rc.counts, counts_bytes, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                seg_closest += (uint64_t)n_pix * rc.pass_samples;
+                for (uint32_t b = 0; b < p.max_depth; ++b) {
+                    seg_shadow += h_counts[4 * b + 1];
+                    if (b + 1 < p.max_depth) seg_closest += h_counts[4 * b + 2];
+                }
+            }
+        }
+        begin(SPT_K_RESOLVE);
+        hipLaunchKernelGGL(k_finish, dim3((n_pix * 3 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, sc->out.as<float>());
+        end();
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(rgb_mean_out, sc->out.p, (size_t)n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(ev_total1, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (stats) {
+            stats->samples = (uint64_t)n_pix * p.spp;
+            stats->segments_closest = seg_closest;
+            stats->segments_shadow = seg_shadow;
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_total0, ev_total1));
+            stats->gpu_ms = ms;
+            for (auto& sp : spans) {
+                float k = 0.0f;
+                HIP_CHECK(hipEventElapsedTime(&k, sc->events[sp.e0], sc->events[sp.e0 + 1]));
+                stats->kernel_ms[sp.cls] += k;
+                stats->kernel_launches[sp.cls] += 1;
+            }
+        }
+        return SPT_OK;
+    } catch (const AbiError& e) {
+        g_error = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_error = std::string("render: ") + e.what();
+        return SPT_ERR_OUT_OF_MEMORY;
+    }
+}
+
+static spt_status trace_common(const spt_scene* scene_c, uint32_t n, const spt_ray* rays, void* out, size_t out_elem, bool closest) {
+    if (!scene_c || (n && (!rays || !out))) { g_error = "trace: null argument"; return SPT_ERR_INVALID_ARG; }
+    if (n == 0) return SPT_OK;
+    spt_scene* sc = const_cast<spt_scene*>(scene_c);
+    std::lock_guard<std::mutex> lock(sc->mu);
+    try {
+        HIP_CHECK(hipSetDevice(sc->device));
+        sc->trace_in.ensure((size_t)n * sizeof(spt_ray));
+        sc->trace_out.ensure((size_t)n * out_elem);
+        hipStream_t st = sc->stream;
+        HIP_CHECK(hipMemcpyAsync(sc->trace_in.p, rays, (size_t)n * sizeof(spt_ray), hipMemcpyHostToDevice, st));
+        const size_t lds = (size_t)sc->d.stack_cap * kBlock * sizeof(uint32_t);
+        dim3 grid((n + kBlock - 1) / kBlock);
+        if (closest)
+            hipLaunchKernelGGL(k_trace_closest, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
+        else
+            hipLaunchKernelGGL(k_trace_any, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<uint8_t>());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, sc->trace_out.p, (size_t)n * out_elem, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return SPT_OK;
+    } catch (const AbiError& e) {
+        g_error = e.msg;
+        return e.code;
+    }
+}
+
+spt_status spt_trace_closest(const spt_scene* scene, uint32_t n, const spt_ray* rays, spt_hit* hits) {
+    return trace_common(scene, n, rays, hits, sizeof(spt_hit), true);
+}
+spt_status spt_trace_any(const spt_scene* scene, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
+    return trace_common(scene, n, rays, occluded, 1, false);
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+The oracle runs with ORACLE_SLAB_RECIPROCAL (the kernels' slab arithmetic); everything else
+is the reference-order restatement.  Integer/index results must be bit-exact; radiance is
+f32 and is expected bit-exact too (shared deterministic math, no FP contraction), with the
+north-star tolerance (per-pixel mean L1 < 1e-3) as the hard gate.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _util
+
+pytestmark = pytest.mark.gpu
+
+L1_TOL = 1e-3  # BASELINE.json north_star: per-pixel mean L1 < 1e-3
+
+
+@pytest.fixture(scope="module")
+def spt():
+    return _util.load_pkg()
+
+
+def _scene(spt, name):
+    return spt.load_scene(os.path.join(_util.SCENES, name))
+
+
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json"])
+def test_trace_closest_and_any_bit_exact(spt, scene_name):
+    sc = _scene(spt, scene_name)
+    rays = _util.random_rays(sc, 200_000, seed=11)
+    ref = _util.oracle_trace_closest(sc, rays, _util.ORACLE_SLAB_RECIPROCAL)
+    got = sc.device_scene(0).trace_closest(rays)
+    assert ref["instance"].max() >= 0, "test rays never hit"
+    assert np.array_equal(ref["instance"], got["instance"])
+    assert np.array_equal(ref["prim"], got["prim"])
+    assert np.array_equal(ref["t"].view(np.uint32), got["t"].view(np.uint32))
+    assert np.array_equal(ref["v"].view(np.uint32), got["v"].view(np.uint32))
+    assert np.array_equal(ref["w"].view(np.uint32), got["w"].view(np.uint32))
+    # any-hit with finite t_max taken around the closest hits
+    rays2 = rays.copy()
+    rays2["t_max"] = np.where(ref["instance"] >= 0, ref["t"] * np.float32(1.5), np.float32(5.0)).astype(np.float32)
+    rays2["t_max"][::2] = (rays2["t_max"][::2] * np.float32(0.5)).astype(np.float32)
+    occ_ref = _util.oracle_trace_any(sc, rays2, _util.ORACLE_SLAB_RECIPROCAL)
+    occ = sc.device_scene(0).trace_any(rays2)
+    assert 0 < occ_ref.sum() < len(occ_ref)
+    assert np.array_equal(occ_ref, occ)
+
+
+def test_trace_empty_batch(spt):
+    sc = _scene(spt, "cfg2_cube.json")
+    rays = np.zeros(0, dtype=spt.RAY_DTYPE)
+    assert sc.device_scene(0).trace_closest(rays).shape == (0,)
+    assert sc.device_scene(0).trace_any(rays).shape == (0,)
+
+
+@pytest.mark.parametrize("scene_name,size,spp", [("cfg1_sphere.json", (96, 64), 16), ("cfg2_cube.json", (128, 128), 16)])
+@pytest.mark.parametrize("sampler", ["recurrence", "random"])
+def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
+    sc = _scene(spt, scene_name)
+    r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RECURRENCE if sampler == "recurrence" else spt.SAMPLER_RANDOM,
+                       spp=spp, seed=7)
+    w, h = size
+    ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.ORACLE_SLAB_RECIPROCAL)
+    got = r.render_shard(sc, spt.OutputConfig(w, h), samples_per_pass=5)  # 16 = 5+5+5+1: exercises the pass loop
+    l1 = float(np.abs(got - ref).mean())
+    assert l1 < L1_TOL, l1
+    assert ref.max() > 0.1
+    mism = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    assert mism == 0, "radiance not bit-exact: %d words differ, L1 %.3g" % (mism, l1)
+
+
+def test_shard_layout_does_not_change_pixels(spt):
+    sc = _scene(spt, "cfg2_cube.json")
+    r = spt.PathTracer(max_depth=8, spp=8, seed=3)
+    w, h = 96, 80
+    full = r.render_shard(sc, spt.OutputConfig(w, h))
+    out = np.zeros_like(full)
+    for k in range(3):
+        rows = spt.shard_rows(h, k, 3, 16)
+        out[rows] = r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=3, strip_rows=16)
+    assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
+
+
+def test_render_error_paths(spt):
+    sc = _scene(spt, "cfg2_cube.json")
+    r = spt.PathTracer(max_depth=8, spp=4)
+    with pytest.raises(spt.SptError):
+        r.render_shard(sc, spt.OutputConfig(0, 16))
+    with pytest.raises(spt.SptError):
+        r.render_shard(sc, spt.OutputConfig(16, 16), shard_index=2, shard_count=2)
+    r2 = spt.PathTracer(max_depth=300, spp=4)
+    with pytest.raises(spt.SptError):
+        r2.render_shard(sc, spt.OutputConfig(16, 16))
