@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the path-tracing hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): the reference's scenes/test_scene_01.json
+(re-authored as scenes_amd/cfg2_cube.json: 12-triangle Lambert cube, one directional
+light) with scenes/pt.json (max_depth 8, recurrence sampler, box filter 0.5) at
+1024x1024, 256 spp on one GPU.  A "step" is one full render of that image.
+
+N > 1 (weak scaling): the image stays 1024x1024 and spp becomes 256*N; image rows are
+sharded over the ranks in interleaved 16-row strips, so every rank traces the same
+268.4 M camera samples per step with the same scene coverage.  There is no data-path
+collective; the shards are gathered on the host of rank 0 inside the timed region.
+
+Launch: `python bench.py` (N=1) or, for N>1,
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+ --master-port P bench.py --gpus N --steps K --warmup W`.
+PyTorch is used only for the barrier / synchronize / gather plumbing.
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_pkg():
+    name = "simple_path_tracer_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "simple-path-tracer_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# record sizes of the queue layouts in simple-path-tracer_amd/csrc/hip/kernels.h (bytes)
+S_PATH, S_HIT, S_SHADOW, S_RAD = 72, 20, 48, 12
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(spt, scene, renderer, width, height, budget_s=15.0):
+    """Oracle (CPU restatement of the reference loop) timed on this box's host cores, on a
+    bounded sample of the SAME workload: the full 1024x1024 frame at a reduced spp."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _util
+
+    _util.ensure_cpu_build()
+    cores = len(os.sched_getaffinity(0))
+    threads = 2 * cores  # reference layout: num_cpus * 2 threads over row bands (pt.rs:243)
+    probe = spt.PathTracer(renderer.max_depth, renderer.sampler, 1, 0, 0, renderer.filter_radius, renderer.seed)
+    t0 = time.perf_counter()
+    _util.oracle_render(scene, probe, width, height, threads=threads)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    spp = int(max(1, min(renderer.spp, budget_s / dt)))
+    run = spt.PathTracer(renderer.max_depth, renderer.sampler, spp, 0, 0, renderer.filter_radius, renderer.seed)
+    t0 = time.perf_counter()
+    _, st = _util.oracle_render(scene, run, width, height, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(st.samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "threads": threads,
+        "kind": "port",
+        "sample": "%dx%d @ %d spp of the same scene/renderer (%.1f s, %d samples)" % (width, height, spp, dt, st.samples),
+    }, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU-share")
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes_amd", "cfg2_cube.json"))
+    ap.add_argument("--renderer", default=os.path.join(ROOT, "scenes_amd", "pt.json"))
+    ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+
+    spt = load_pkg()
+    scene = spt.load_scene(args.scene)
+    renderer = spt.load_renderer(args.renderer, seed=1)
+    renderer.spp = args.spp * world
+    cfg = spt.OutputConfig(args.width, args.height)
+    strip_rows = 16
+    # scene upload (excluded from the timed region: inputs resident in HBM)
+    scene.device_scene(local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    rows_all = [spt.shard_rows(args.height, r, world, strip_rows) for r in range(world)]
+    full = np.zeros((args.height, args.width, 3), dtype=np.float32) if rank == 0 else None
+    kernel_ms = np.zeros(spt.N_KERNELS)
+    kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
+    stats_last = None
+
+    def step(timed):
+        nonlocal stats_last
+        shard = renderer.render_shard(scene, cfg, device=local_rank, shard_index=rank, shard_count=world,
+                                      strip_rows=strip_rows, samples_per_pass=args.samples_per_pass,
+                                      profile=not args.no_profile)
+        st = renderer.last_stats
+        if timed:
+            for k in range(spt.N_KERNELS):
+                kernel_ms[k] += st.kernel_ms[k]
+                kernel_launches[k] += st.kernel_launches[k]
+        stats_last = st
+        # host-side gather of the shards (no reduction: rows are disjoint)
+        if dist is None:
+            full[rows_all[0]] = shard
+        else:
+            t = torch.from_numpy(shard)
+            if rank == 0:
+                bufs = [torch.empty((len(rows_all[r]), args.width, 3), dtype=torch.float32) for r in range(world)]
+                dist.gather(t, bufs, dst=0)
+                for r in range(world):
+                    full[rows_all[r]] = bufs[r].numpy()
+            else:
+                dist.gather(t, None, dst=0)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        samples_per_step = args.width * args.height * renderer.spp  # all ranks together
+        ms_per_step = dt / args.steps * 1e3
+        value = samples_per_step * args.steps / dt / 1e6
+        st = stats_last
+        # per-launch algorithmic bytes of each kernel class ("Kernels and rooflines"), rank 0's shard
+        n_launch = np.maximum(kernel_launches, 1)
+        seg_c, seg_s, smp = st.segments_closest, st.segments_shadow, st.samples
+        ext = seg_c - smp                       # extension segments
+        hits0 = None
+        alg_bytes = {
+            # primary: writes one path + hit record and one radiance slot per primary hit; film RMW per pass
+            # (primary hits are not counted separately by the ABI: bounded above by shade work = ext + deaths;
+            #  use the measured shadow+ext segment counts as the per-hit traffic instead)
+            "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
+            "extend": ext * (S_PATH + S_PATH + S_HIT),
+        }
+        dom = int(np.argmax(kernel_ms[:5])) if kernel_ms.sum() > 0 else 0
+        dom_name = spt.KERNEL_NAMES[dom]
+        avg_ms = float(kernel_ms[dom] / n_launch[dom]) if kernel_ms[dom] > 0 else None
+        # whole-pipeline algorithmic bytes per sample (SURVEY 8d formula with this build's record sizes)
+        bytes_per_sample = ((seg_c - ext) * 0.0 + ext * 2 * (S_PATH + S_HIT) + seg_s * 2 * S_SHADOW) / max(smp, 1) \
+            + 2 * (S_PATH + S_HIT) * 1.0
+        pipeline_gbs = bytes_per_sample * value * 1e6 / 1e9 / world
+        roofline = {
+            "bound": "hbm", "kernel": "k_" + dom_name,
+            "achieved": round(pipeline_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(pipeline_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+            "kernel_avg_ms": {spt.KERNEL_NAMES[k]: round(float(kernel_ms[k] / n_launch[k]), 4) for k in range(5) if kernel_launches[k]},
+            "kernel_share": {spt.KERNEL_NAMES[k]: round(float(kernel_ms[k] / max(kernel_ms.sum(), 1e-9)), 4) for k in range(spt.N_KERNELS)},
+            "dominant_kernel_avg_ms": avg_ms,
+            "note": "achieved = algorithmic queue bytes/sample (SURVEY 8d) x samples/s per GPU; the path is ALU/latency-bound, see DESIGN.md",
+        }
+        out = {
+            "metric": "Msamples/sec (whole node) at 1024x1024/256spp; per-pixel mean L1 vs CPU ref",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "scenes_amd/cfg2_cube.json (= reference scenes/test_scene_01.json) + pt.json, "
+                                   "%dx%d @ %d spp (%d spp per GPU-share), max_depth %d, recurrence sampler"
+                                   % (args.width, args.height, renderer.spp, args.spp, renderer.max_depth),
+                       "width": args.width, "height": args.height, "spp": renderer.spp, "seed": 1,
+                       "sharding": "interleaved %d-row strips over %d rank(s), host-side gather" % (strip_rows, world),
+                       "segments_per_sample": round((seg_c + seg_s) / max(smp, 1), 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ost = cpu_baseline(spt, scene, spt.load_renderer(args.renderer, seed=1), args.width, args.height)
+            out["cpu_baseline"] = base
+            out["config"]["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,8 @@ struct RenderCtx {
     PathQueue qa, qb;         // qa: paths with a hit record (input of shade); qb: paths to extend
     HitQueue hits;
     ShadowQueue shadow;
-    uint32_t* counts;         // [bounce][4] = {hit-queue length, shadow length, ext length, -}
+    uint32_t* counts;         // [bounce][3 queues][kShards] lengths, one 128-B line each (see q_count)
+    uint32_t shard_cap;       // entries per queue shard
     float* rad;               // 3 planes [c][s][pixel] of per-sample radiance
     float* film;              // n_pixels * 3 running sums
     uint32_t* first_slot;     // per pixel: first sample of the pass that uses a rad slot
@@ -72,6 +73,18 @@ struct RenderCtx {
 };
 
 SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Every queue is split into kShards sub-queues with their own length counter on their
+// own 128-byte line: a block only ever appends to / consumes shard (blockIdx.x % kShards).
+//  - one hot counter would serialise every wave's append in the L2 atomic unit;
+//  - blocks b and b+8 run on the same XCD (round-robin dispatch), so with kShards a
+//    multiple of 8 a shard is written and later read by blocks of ONE XCD and its
+//    records stay in that XCD's 4 MiB L2 between stages (speed only, never correctness).
+constexpr uint32_t kShards = 64;
+enum { Q_HIT = 0, Q_SHADOW = 1, Q_EXT = 2 };
+SPT_DEV uint32_t* q_count(const uint32_t* counts, uint32_t bounce, uint32_t q, uint32_t shard) {
+    return const_cast<uint32_t*>(counts) + ((size_t)(bounce * 3u + q) * kShards + shard) * 32u;
+}
 
 // Wave-aggregated append: returns this lane's slot (valid only where pred).
 SPT_DEV uint32_t wave_push(bool pred, uint32_t* counter) {
@@ -131,6 +144,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
     const uint32_t pixel = j * rc.width + i;
     const bool has_env = sc.env_w != 0u;
+    const uint32_t shard = blockIdx.x % kShards;
     f3 sum = mk3(0, 0, 0);
     if (valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
     uint32_t first = rc.pass_samples;
@@ -168,7 +182,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
             if (first == rc.pass_samples) first = s;
             rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
         }
-        uint32_t slot = wave_push(hit, &rc.counts[0]);
+        uint32_t slot = shard * rc.shard_cap + wave_push(hit, q_count(rc.counts, 0, Q_HIT, shard));
         if (hit) {
             store_path(rc.qa, slot, ray, 0.0f, gray(1.0f), (uint32_t)ri, mk3(0, 0, 0), pack_meta(0u, -1), rng);
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
@@ -192,13 +206,15 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // One iteration of the `while curr_depth < max_depth` loop of trace_ray, minus the
 // two traversals, for the path vertex in qa[idx] / hits[idx].
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
-    const uint32_t n = rc.counts[4 * bounce + 0];
-    uint32_t* shadow_count = &rc.counts[4 * bounce + 1];
-    uint32_t* ext_count = &rc.counts[4 * bounce + 2];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
-        const uint32_t idx = i0 + lane_id();
-        const bool active = idx < n;
+    const uint32_t shard = blockIdx.x % kShards;
+    const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
+    uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
+    uint32_t* ext_count = q_count(rc.counts, bounce, Q_EXT, shard);
+    const uint32_t qbase = shard * rc.shard_cap;
+    const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
+    for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const bool active = i0 + lane_id() < n;
+        const uint32_t idx = qbase + i0 + lane_id();
         bool want_shadow = false, want_ext = false;
         DRay shadow_ray, next_ray;
         float shadow_tmax = 0.0f, next_pdf = 0.0f;
@@ -385,22 +401,25 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 }
             }
         }
-        uint32_t ss = wave_push(want_shadow, shadow_count);
+        uint32_t ss = qbase + wave_push(want_shadow, shadow_count);
         if (want_shadow) {
             rc.shadow.o_tmin[ss] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.t_min);
             rc.shadow.d_tmax[ss] = make_float4(shadow_ray.d.x, shadow_ray.d.y, shadow_ray.d.z, shadow_tmax);
             rc.shadow.contrib_slot[ss] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
         }
-        uint32_t es = wave_push(want_ext, ext_count);
+        uint32_t es = qbase + wave_push(want_ext, ext_count);
         if (want_ext) store_path(rc.qb, es, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
     }
 }
 
 // ---------------------------------------------------------------------------- shadow
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
-    const uint32_t n = rc.counts[4 * bounce + 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const uint32_t shard = blockIdx.x % kShards;
+    const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
+    const uint32_t qbase = shard * rc.shard_cap;
+    const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
+    for (uint32_t i = (blockIdx.x / kShards) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t idx = qbase + i;
         float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx], c = rc.shadow.contrib_slot[idx];
         DRay r;
         r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
@@ -410,12 +429,14 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_
 
 // ---------------------------------------------------------------------------- extend
 __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
-    const uint32_t n = rc.counts[4 * bounce + 2];
-    uint32_t* next_count = &rc.counts[4 * (bounce + 1) + 0];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
-        const uint32_t idx = i0 + lane_id();
-        const bool active = idx < n;
+    const uint32_t shard = blockIdx.x % kShards;
+    const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
+    uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
+    const uint32_t qbase = shard * rc.shard_cap;
+    const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
+    for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const bool active = i0 + lane_id() < n;
+        const uint32_t idx = qbase + i0 + lane_id();
         bool keep = false;
         float4 a, b, c, d;
         uint2 rs;
@@ -439,7 +460,7 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
                 rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
             }
         }
-        uint32_t slot = wave_push(keep, next_count);
+        uint32_t slot = qbase + wave_push(keep, next_count);
         if (keep) {
             rc.qa.o_tmin[slot] = a; rc.qa.d_pdf[slot] = b; rc.qa.thr_slot[slot] = c; rc.qa.lsi_meta[slot] = d;
             rc.qa.rng[slot] = rs;

@@ -342,13 +342,18 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         // samples per pass: keep the queues around a few million entries
         uint32_t spp_pass = p.samples_per_pass;
         if (spp_pass == 0) {
-            const uint64_t target = 8ull << 20;
+            const uint64_t target = 32ull << 20;
             spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
         }
         spp_pass = std::min(spp_pass, p.spp);
-        const uint64_t cap64 = (uint64_t)n_pix * spp_pass;
+        // queue shards: shard s holds what the primary blocks b = s (mod kShards) can emit, which also
+        // bounds every later generation of that shard
+        const uint32_t pix_blocks = (n_pix + kBlock - 1) / kBlock;
+        const uint64_t shard_cap64 = (uint64_t)((pix_blocks + kShards - 1) / kShards) * kBlock * spp_pass;
+        const uint64_t cap64 = shard_cap64 * kShards;
         if (cap64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: pass too large (lower samples_per_pass)");
         const size_t cap = (size_t)cap64;
+        const uint64_t rad64 = (uint64_t)n_pix * spp_pass;
 
         for (int k = 0; k < 4; ++k) { sc->qa[k].ensure(cap * 16); sc->qb[k].ensure(cap * 16); }
         sc->qa[4].ensure(cap * 8);
@@ -356,9 +361,10 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         sc->hit_f4.ensure(cap * 16);
         sc->hit_inst.ensure(cap * 4);
         for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
-        const size_t counts_bytes = (size_t)(p.max_depth + 2) * 4 * sizeof(uint32_t);
+        const size_t counts_words = (size_t)(p.max_depth + 1) * 3 * kShards * 32;
+        const size_t counts_bytes = counts_words * sizeof(uint32_t);
         sc->counts.ensure(counts_bytes);
-        sc->rad.ensure(cap * 3 * sizeof(float));
+        sc->rad.ensure((size_t)rad64 * 3 * sizeof(float));
         sc->film.ensure((size_t)n_pix * 3 * sizeof(float));
         sc->first_slot.ensure((size_t)n_pix * sizeof(uint32_t));
         sc->out.ensure((size_t)n_pix * 3 * sizeof(float));
@@ -379,6 +385,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
         rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
         rc.counts = sc->counts.as<uint32_t>();
+        rc.shard_cap = (uint32_t)shard_cap64;
         rc.rad = sc->rad.as<float>();
         rc.film = sc->film.as<float>();
         rc.first_slot = sc->first_slot.as<uint32_t>();
@@ -390,7 +397,6 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         hipStream_t st = sc->stream;
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
         const size_t lds = (size_t)sc->d.stack_cap * kBlock * sizeof(uint32_t);
-        const uint32_t pix_blocks = (n_pix + kBlock - 1) / kBlock;
         struct Span { int cls; size_t e0; };
         std::vector<Span> spans;
         size_t ev_used = 0;
@@ -442,13 +448,18 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
             end();
             if (stats) {
-                h_counts.resize((size_t)(p.max_depth + 2) * 4);
+                h_counts.resize(counts_words);
                 HIP_CHECK(hipMemcpyAsync(h_counts.data(), rc.counts, counts_bytes, hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
                 seg_closest += (uint64_t)n_pix * rc.pass_samples;
+                auto qsum = [&](uint32_t b, uint32_t q) {
+                    uint64_t t = 0;
+                    for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * 3 + q) * kShards + s) * 32];
+                    return t;
+                };
                 for (uint32_t b = 0; b < p.max_depth; ++b) {
-                    seg_shadow += h_counts[4 * b + 1];
-                    if (b + 1 < p.max_depth) seg_closest += h_counts[4 * b + 2];
+                    seg_shadow += qsum(b, Q_SHADOW);
+                    if (b + 1 < p.max_depth) seg_closest += qsum(b, Q_EXT);
                 }
             }
         }
