@@ -115,8 +115,6 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    rows_all = [spt.shard_rows(args.height, r, world, strip_rows) for r in range(world)]
-    full = np.zeros((args.height, args.width, 3), dtype=np.float32) if rank == 0 else None
     kernel_ms = np.zeros(spt.N_KERNELS)
     kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
     stats_last = None
@@ -133,17 +131,7 @@ def main():
                 kernel_launches[k] += st.kernel_launches[k]
         stats_last = st
         # host-side gather of the shards (no reduction: rows are disjoint)
-        if dist is None:
-            full[rows_all[0]] = shard
-        else:
-            t = torch.from_numpy(shard)
-            if rank == 0:
-                bufs = [torch.empty((len(rows_all[r]), args.width, 3), dtype=torch.float32) for r in range(world)]
-                dist.gather(t, bufs, dst=0)
-                for r in range(world):
-                    full[rows_all[r]] = bufs[r].numpy()
-            else:
-                dist.gather(t, None, dst=0)
+        return spt.gather_shards(shard, args.height, args.width, rank, world, strip_rows, dist)
 
     for _ in range(args.warmup):
         step(False)

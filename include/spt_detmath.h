@@ -80,7 +80,8 @@ SPT_HD float spt_floor(float x) {
 /* Rust f32::round: half away from zero (|x| < 2^23 in our uses). */
 SPT_HD float spt_round(float x) {
     float a = spt_abs(x);
-    float r = spt_floor(a + 0.5f);
+    float f = spt_floor(a);
+    float r = (a - f >= 0.5f) ? f + 1.0f : f; /* a - f is exact; a + 0.5f could round up */
     return (x < 0.0f) ? -r : r;
 }
 

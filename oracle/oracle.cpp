@@ -273,6 +273,8 @@ inline bool sphere_intersect(const Ctx& cx, uint32_t si, const Ray& ray, Inter& 
             sphere_frame(norm, &inter.tangent, &inter.bitangent);
             inter.prim = (int32_t)si;
             inter.prim_type = SPT_PRIM_SPHERE;
+            inter.bv = 0.0f;
+            inter.bw = 0.0f;
             return true;
         }
     }

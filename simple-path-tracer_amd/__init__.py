@@ -415,6 +415,35 @@ def write_exr(path: str, rgb: np.ndarray) -> None:
     _check_host(host_lib().spt_host_write_exr(os.fspath(path).encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
 
 
+def gather_shards(shard: np.ndarray, height: int, width: int, rank: int, world: int, strip_rows: int, dist=None):
+    """Host-side gather of the per-rank row shards into the full (H, W, 3) film on rank 0.
+
+    Shards are disjoint sets of image rows (interleaved strips), so this is a concatenation, not a
+    reduction; `dist` is torch.distributed (its CPU/gloo path is used) or None for a single rank.
+    Returns the film on rank 0 and None elsewhere.  (The reference has one address space and no
+    counterpart; cf. UnsafeFilm, src/core/film.rs:101-116.)"""
+    rows_all = [shard_rows(height, r, world, strip_rows) for r in range(world)]
+    assert shard.shape == (len(rows_all[rank]), width, 3), (shard.shape, len(rows_all[rank]))
+    if world == 1 or dist is None:
+        full = np.zeros((height, width, 3), dtype=np.float32)
+        full[rows_all[0]] = shard
+        return full
+    import torch
+    max_rows = max(len(r) for r in rows_all)          # gather needs equal shapes: pad short shards
+    padded = np.zeros((max_rows, width, 3), dtype=np.float32)
+    padded[: shard.shape[0]] = shard
+    t = torch.from_numpy(padded)
+    if rank == 0:
+        bufs = [torch.empty((max_rows, width, 3), dtype=torch.float32) for _ in range(world)]
+        dist.gather(t, bufs, dst=0)
+        full = np.zeros((height, width, 3), dtype=np.float32)
+        for r in range(world):
+            full[rows_all[r]] = bufs[r].numpy()[: len(rows_all[r])]
+        return full
+    dist.gather(t, None, dst=0)
+    return None
+
+
 def device_count() -> int:
     n = C.c_int32()
     _check_hip(hip_lib().spt_device_count(C.byref(n)))

@@ -26,7 +26,7 @@ def _scene(spt, name):
     return spt.load_scene(os.path.join(_util.SCENES, name))
 
 
-@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json"])
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json"])
 def test_trace_closest_and_any_bit_exact(spt, scene_name):
     sc = _scene(spt, scene_name)
     rays = _util.random_rays(sc, 200_000, seed=11)
@@ -67,6 +67,26 @@ def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
     l1 = float(np.abs(got - ref).mean())
     assert l1 < L1_TOL, l1
     assert ref.max() > 0.1
+    mism = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    assert mism == 0, "radiance not bit-exact: %d words differ, L1 %.3g" % (mism, l1)
+
+
+@pytest.mark.parametrize("scene_name,camera,sampler", [
+    ("t_materials.json", "main", "random"),      # GGX conductor (iso + aniso), mirror, rough + smooth glass, env MIS,
+    ("t_materials.json", "top", "jittered"),     #   dir/point/spot/shape lights, uniform light sampler, TLAS
+    ("t_power_is.json", "main", "recurrence"),   # power_is alias-table sampler, colour environment, group aggregate
+    ("t_medium.json", None, "random"),           # homogeneous media (HG g=0.3 and isotropic), pseudo boundary, area light
+])
+def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
+    sc = _scene(spt, scene_name)
+    kinds = {"random": spt.SAMPLER_RANDOM, "recurrence": spt.SAMPLER_RECURRENCE, "jittered": spt.SAMPLER_JITTERED}
+    r = spt.PathTracer(max_depth=8, sampler=kinds[sampler], spp=16, division_x=4, division_y=4, seed=21)
+    w, h = 160, 120
+    ref, _ = _util.oracle_render(sc, r, w, h, camera=camera, flags=_util.ORACLE_SLAB_RECIPROCAL)
+    got = r.render_shard(sc, spt.OutputConfig(w, h, None, camera), samples_per_pass=6)
+    assert np.isfinite(ref).all()
+    l1 = float(np.abs(got - ref).mean())
+    assert l1 < L1_TOL, l1
     mism = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     assert mism == 0, "radiance not bit-exact: %d words differ, L1 %.3g" % (mism, l1)
 

@@ -1,0 +1,232 @@
+"""Host side (libspt_host.so): scene / renderer JSON loading with the reference's semantics
+(src/loader/json.rs, src/core/loader.rs, src/core/scene_resources.rs, src/primitive/instance.rs)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _util
+
+spt = _util.load_pkg()
+REF = "/root/reference/scenes"
+
+BASE = {
+    "cameras": {"type": "perspective", "name": "c", "eye": [0.0, 0.0, 5.0], "forward": [0.0, 0.0, -1.0], "up": [0.0, 1.0, 0.0], "fov": 45.0},
+    "textures": [{"type": "scalar", "name": "w", "value": [1.0, 0.5, 0.25]}],
+    "materials": [{"type": "lambert", "name": "m", "albedo": "w"}],
+    "mediums": [], "surfaces": [],
+    "primitives": [{"type": "sphere", "name": "s", "radius": 1.0}],
+    "instances": [{"name": "i", "primitive": "s", "material": "m"}],
+    "lights": [{"type": "directional", "name": "l", "direction": [0.0, -2.0, 0.0], "strength": [1.0, 1.0, 1.0]}],
+}
+
+
+def load(tmp_path, scene, name="scene.json"):
+    p = tmp_path / name
+    p.write_text(json.dumps(scene))
+    return spt.load_scene(str(p))
+
+
+def test_camera_basis_and_light_normalisation(tmp_path):
+    sc = load(tmp_path, BASE)
+    cam = sc.get_camera()
+    assert list(cam.forward) == [0.0, 0.0, -1.0] and list(cam.right)[0] == 1.0 and list(cam.up)[1] == 1.0
+    assert abs(cam.half_cot_half_fov - 0.5 / np.tan(np.radians(22.5))) < 1e-6
+    assert np.allclose(sc.array("lights")["dir"][0], [0.0, -1.0, 0.0])      # DirLight::new normalises
+    assert sc.desc.aggregate == 1 and sc.desc.light_sampler == 0            # defaults: bvh, uniform
+
+
+def test_missing_and_mistyped_fields_fail_like_the_reference(tmp_path):
+    for key in ("cameras", "textures", "materials", "mediums", "primitives", "surfaces", "instances", "lights"):
+        bad = {k: v for k, v in BASE.items() if k != key}
+        with pytest.raises(spt.SptError) as e:
+            load(tmp_path, bad)
+        assert e.value.status == 102 and key in str(e.value)
+    # JSON integer where a float is required: get_float fails (src/core/loader.rs:286-299) ...
+    bad = json.loads(json.dumps(BASE))
+    bad["primitives"][0]["radius"] = 1
+    with pytest.raises(spt.SptError) as e:
+        load(tmp_path, bad)
+    assert "should be float" in str(e.value)
+    # ... but get_float3_or silently falls back (sphere centre default 0)
+    ok = json.loads(json.dumps(BASE))
+    ok["primitives"][0]["center"] = [1, 2, 3]
+    assert np.allclose(load(tmp_path, ok).array("spheres")["center"][0], [0, 0, 0])
+    for mutate, msg in (
+        (lambda s: s["materials"][0].update(albedo="nope"), "no texture named"),
+        (lambda s: s["instances"][0].update(primitive="nope"), "no primitive named"),
+        (lambda s: s["instances"].append(dict(s["instances"][0])), "Duplicated instance"),
+        (lambda s: s["primitives"][0].update(type="torus"), "unknown type"),
+        (lambda s: s.update(aggregate="octree"), "Unknown aggregate"),
+        (lambda s: s.update(light_sampler="best"), "Unknown light sampler"),
+        (lambda s: s.update(cameras=[]), "At least one camera"),
+    ):
+        bad = json.loads(json.dumps(BASE))
+        mutate(bad)
+        with pytest.raises(spt.SptError) as e:
+            load(tmp_path, bad)
+        assert msg in str(e.value), str(e.value)
+    with pytest.raises(spt.SptError) as e:
+        spt.load_scene(str(tmp_path / "missing.json"))
+    assert e.value.status == 100
+
+
+def test_out_of_scope_features_are_reported_not_ignored(tmp_path):
+    for mutate in (lambda s: s["textures"].append({"type": "image", "name": "t", "image_file": "x.png"}),
+                   lambda s: s["materials"].append({"type": "plastic", "name": "p"}),
+                   lambda s: s["primitives"].append({"type": "catmull_clark", "name": "cc", "ply_file": "x.ply"}),
+                   lambda s: s.update(gltf="x.gltf")):
+        bad = json.loads(json.dumps(BASE))
+        mutate(bad)
+        with pytest.raises(spt.SptError) as e:
+            load(tmp_path, bad)
+        assert e.value.status == 103
+
+
+def test_sections_as_external_files_nested_arrays_and_comments(tmp_path):
+    sc = json.loads(json.dumps(BASE))
+    (tmp_path / "mats.json").write_text(json.dumps([[sc["materials"][0]], []]))
+    sc["materials"] = "mats.json"
+    sc["textures"][0]["#note"] = "keys starting with # are comments"
+    sc["textures"][0]["tiling"] = [2.0, 2.0]            # TexInputModifier on a constant texture: identity
+    got = load(tmp_path, sc)
+    assert np.allclose(got.array("materials")["c0"][0], [1.0, 0.5, 0.25])
+    sc["materials"] = "nope.json"
+    with pytest.raises(spt.SptError) as e:
+        load(tmp_path, sc)
+    assert "External json file not found" in str(e.value)
+
+
+def test_instance_transform_order_is_T_Rz_Rx_Ry_S_M(tmp_path):
+    sc = json.loads(json.dumps(BASE))
+    sc["instances"][0].update(scale=[2.0, 3.0, 4.0], rotate=[10.0, 20.0, 30.0], translate=[1.0, 2.0, 3.0],
+                              matrix=[1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.5, 0.0, 0.0, 1.0])
+    inst = load(tmp_path, sc).array("instances")[0]
+    rx, ry, rz = np.radians([10.0, 20.0, 30.0])
+    Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+    Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+    Rz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
+    M = Rz @ Rx @ Ry @ np.diag([2.0, 3.0, 4.0])
+    fwd = inst["fwd"].reshape(4, 3)             # three columns + translation
+    assert np.allclose(fwd[:3].T, M, atol=1e-5)
+    assert np.allclose(fwd[3], M @ np.array([0.5, 0, 0]) + np.array([1.0, 2.0, 3.0]), atol=1e-5)
+    inv = inst["inv"].reshape(4, 3)
+    assert np.allclose(inv[:3].T @ M, np.eye(3), atol=1e-5)
+    assert np.allclose(inst["nrm"].reshape(3, 3).T, np.linalg.inv(M).T, atol=1e-5)   # trans_it
+
+
+def test_obj_single_index_triangulation_and_tangents(tmp_path):
+    (tmp_path / "q.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\n"
+                                    "f 1/1/1 2/2/1 3/3/1 4/4/1\nf -4/1/1 -3/2/1 -1/4/1\n")
+    sc = json.loads(json.dumps(BASE))
+    sc["primitives"] = [{"type": "trimesh", "name": "s", "obj_file": "q.obj"}]
+    got = load(tmp_path, sc)
+    assert got.desc.n_tris == 3                      # quad fanned into 2 + 1 triangle
+    attr = got.array("tri_attr")
+    assert np.allclose(attr["n"], [0, 0, 1])
+    assert np.allclose(attr["t"], [1, 0, 0], atol=1e-6) and np.allclose(attr["b"], [0, 1, 0], atol=1e-6)   # d/du, d/dv
+    pos = got.array("tri_pos")
+    tris = {tuple(map(tuple, np.round([t["p0"], t["p1"], t["p2"]], 3))) for t in pos}
+    assert ((0, 0, 0), (1, 0, 0), (1, 1, 0)) in tris and ((0, 0, 0), (1, 1, 0), (0, 1, 0)) in tris
+
+
+def test_lights_env_first_then_shape_lights_and_power_is_table(tmp_path):
+    sc = spt.load_scene(os.path.join(_util.SCENES, "t_power_is.json"))
+    lights = sc.array("lights")
+    assert lights["type"].tolist() == [4, 1, 2, 0, 3, 3]       # "$env" < bulb < spot < sun, then emissive instances by name
+    assert sc.desc.env_light_index == 0
+    inst = sc.array("instances")
+    for li in (4, 5):
+        assert inst["light"][lights["instance"][li]] == li     # instance_light_map
+    props = np.array([sc.desc.light_alias.props[i] for i in range(6)])
+    assert np.allclose(props, lights["power"] / lights["power"].sum(), rtol=1e-5)
+    # ShapeLight::power = area * luminance(emissive): lamp = Thomsen area of r = 0.35 sphere
+    lamp = lights[4] if inst["prim_type"][lights["instance"][4]] == 0 else lights[5]
+    assert abs(lamp["power"] - 4 * np.pi * 0.35 ** 2 * (0.299 * 14 + 0.587 * 12 + 0.114 * 9)) < 0.05 * lamp["power"]
+
+
+def test_medium_sigma_s_is_read_from_sigma_a_quirk():
+    sc = spt.load_scene(os.path.join(_util.SCENES, "t_medium.json"))
+    fog = sc.array("mediums")[0]
+    assert np.allclose(fog["sigma_s"], [0.25, 0.3, 0.4])       # NOT the "sigma_s": [9,9,9] of the file
+    assert np.allclose(fog["sigma_t"], [0.5, 0.6, 0.8])
+
+
+def test_bvh_leaves_cover_every_triangle_exactly_once():
+    sc = spt.load_scene(os.path.join(_util.SCENES, "t_medium.json"))
+    nodes, meshes, pos = sc.array("blas_nodes"), sc.array("meshes"), sc.array("tri_pos")
+    for m in meshes:
+        seen = np.zeros(m["tri_count"], dtype=int)
+        stack = [int(m["root"])]
+        while stack:
+            nd = nodes[stack.pop()]
+            if nd["b"] & spt.SPT_LEAF_FLAG:
+                cnt = int(nd["b"] & ~np.uint32(spt.SPT_LEAF_FLAG))
+                assert 1 <= cnt <= 4
+                for t in range(int(nd["a"]), int(nd["a"]) + cnt):
+                    seen[t - m["tri_first"]] += 1
+                    for k in ("p0", "p1", "p2"):
+                        assert (pos[t][k] >= nd["bmin"] - 1e-6).all() and (pos[t][k] <= nd["bmax"] + 1e-6).all()
+            else:
+                for ch in (int(nd["a"]), int(nd["b"])):
+                    assert (nodes[ch]["bmin"] >= nd["bmin"] - 1e-6).all() and (nodes[ch]["bmax"] <= nd["bmax"] + 1e-6).all()
+                    stack.append(ch)
+        assert (seen == 1).all()
+
+
+def test_renderer_json(tmp_path):
+    r = spt.load_renderer(os.path.join(_util.SCENES, "pt.json"))
+    assert (r.max_depth, r.spp, r.sampler, r.filter_radius) == (8, 256, spt.SAMPLER_RECURRENCE, 0.5)
+    p = tmp_path / "r.json"
+    p.write_text(json.dumps({"type": "pt", "max_depth": 5, "sampler": {"type": "jittered", "division_x": 3, "division_y": 4}, "filter": {"type": "box", "radius": 0.5}}))
+    r = spt.load_renderer(str(p))
+    assert (r.spp, r.division_x, r.division_y, r.sampler) == (12, 3, 4, spt.SAMPLER_JITTERED)
+    for bad, msg in (({"type": "pt", "max_depth": 5.0, "sampler": {"type": "random", "spp": 4}, "filter": {"type": "box", "radius": 0.5}}, "integer"),
+                     ({"type": "bdpt", "max_depth": 5, "sampler": {"type": "random", "spp": 4}, "filter": {"type": "box", "radius": 0.5}}, "unknown type"),
+                     ({"type": "pt", "max_depth": 5, "sampler": {"type": "random", "spp": 4}, "filter": {"type": "box", "radius": 1}}, "float"),
+                     ({"type": "pt", "max_depth": 5, "filter": {"type": "box", "radius": 0.5}}, "sampler")):
+        p.write_text(json.dumps(bad))
+        with pytest.raises(spt.SptError) as e:
+            spt.load_renderer(str(p))
+        assert msg in str(e.value)
+    wide = spt.PathTracer(filter_radius=1.5)
+    with pytest.raises(spt.SptError):
+        wide.params(8, 8)
+
+
+def test_exr_roundtrip_and_png_and_u8_truncation(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 60, size=(17, 33, 3)).astype(np.float32)
+    spt.write_exr(str(tmp_path / "a.exr"), img)
+    assert np.array_equal(spt.read_exr(str(tmp_path / "a.exr")), img)
+    with pytest.raises(spt.SptError):
+        spt.read_exr(str(tmp_path / "none.exr"))
+    film = np.array([[[0.3333, 0.9999, 1.7], [-0.2, np.nan, 0.5]]], np.float32)
+    assert spt.film_to_rgb8(film).tolist() == [[[84, 254, 255], [0, 0, 127]]]     # trunc, clamp, NaN -> 0 (film.rs:94-99)
+    spt.write_png(str(tmp_path / "a.png"), np.tile(film, (4, 3, 1)))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "a.png")), spt.film_to_rgb8(np.tile(film, (4, 3, 1))))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("mine,theirs", [("cfg1_sphere.json", "test_scene_00.json"), ("cfg2_cube.json", "test_scene_01.json")])
+def test_authored_scenes_equal_the_reference_scenes(mine, theirs):
+    a = spt.load_scene(os.path.join(_util.SCENES, mine))
+    b = spt.load_scene(os.path.join(REF, theirs))
+    ca, cb = a.get_camera(), b.get_camera()
+    for f in ("eye", "forward", "up", "right"):
+        assert list(getattr(ca, f)) == list(getattr(cb, f))
+    assert ca.half_cot_half_fov == cb.half_cot_half_fov
+    for arr in ("lights", "materials", "surfaces", "spheres"):
+        assert a.array(arr).tobytes() == b.array(arr).tobytes()
+    ia, ib = a.array("instances"), b.array("instances")
+    for f in ("inv", "fwd", "nrm", "prim_type", "surface", "bmin", "bmax"):
+        assert np.array_equal(ia[f], ib[f])
+    # same triangle SET (vertex order inside the generated OBJ differs)
+    def tri_set(s):
+        p = s.array("tri_pos")
+        return sorted(tuple(sorted(map(tuple, (t["p0"], t["p1"], t["p2"])))) for t in p)
+    assert tri_set(a) == tri_set(b)
+    if a.desc.n_tris:
+        assert np.allclose(np.abs(a.array("tri_attr")["n"]).sum(), np.abs(b.array("tri_attr")["n"]).sum())
