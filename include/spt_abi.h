@@ -278,6 +278,11 @@ spt_status spt_shard_rows(const spt_render_params* params, uint32_t* rows);
 spt_status spt_trace_closest(const spt_scene* scene, uint32_t n, const spt_ray* rays, spt_hit* hits);
 spt_status spt_trace_any(const spt_scene* scene, uint32_t n, const spt_ray* rays, uint8_t* occluded);
 
+/* Test seam: evaluates one function of include/spt_detmath.h on the device (fn: 0 sin, 1 cos,
+ * 2 log, 3 exp, 4 acos, 5 atan2(a,b), 6 asin, 7 round, 8 floor, 9 sqrt, 10 a/b, 11 max(a,b),
+ * 12 min(a,b)), so the tests can check gfx950 returns the same bits as x86-64. */
+spt_status spt_debug_detmath(int32_t device, uint32_t fn, uint32_t n, const float* a, const float* b, float* out);
+
 const char* spt_last_error(void);
 uint32_t spt_abi_version(void);
 

@@ -1364,6 +1364,10 @@ void oracle_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, flo
         case 6: out[i] = spt_asin(a[i]); break;
         case 7: out[i] = spt_round(a[i]); break;
         case 8: out[i] = spt_floor(a[i]); break;
+        case 9: out[i] = spt_sqrt(a[i]); break;
+        case 10: out[i] = a[i] / b[i]; break;
+        case 11: out[i] = spt_max(a[i], b[i]); break;
+        case 12: out[i] = spt_min(a[i], b[i]); break;
         default: out[i] = 0.0f; break;
         }
     }

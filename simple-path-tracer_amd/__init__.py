@@ -201,6 +201,7 @@ def hip_lib() -> C.CDLL:
         lib.spt_shard_rows.argtypes = [C.POINTER(RenderParams), C.POINTER(C.c_uint32)]
         lib.spt_trace_closest.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.spt_trace_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.spt_debug_detmath.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip_lib = lib
     return _hip_lib
 
@@ -442,6 +443,15 @@ def gather_shards(shard: np.ndarray, height: int, width: int, rank: int, world: 
         return full
     dist.gather(t, None, dst=0)
     return None
+
+
+def device_detmath(fn: int, a: np.ndarray, b: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
+    """Test seam (spt_debug_detmath): include/spt_detmath.h evaluated on the GPU."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)
+    out = np.zeros_like(a)
+    _check_hip(hip_lib().spt_debug_detmath(device, fn, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+    return out
 
 
 def device_count() -> int:

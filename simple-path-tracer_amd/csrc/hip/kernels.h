@@ -59,6 +59,8 @@ struct RenderCtx {
     uint64_t seed;
     uint32_t shard_index, shard_count, strip_rows;
     uint32_t n_pixels;        // pixels of this shard
+    uint32_t rows;            // image rows of this shard (n_pixels = rows * width)
+    uint32_t tiles_x;         // 16x16 tiles per row of tiles
     uint32_t pass_first;      // first sample index of this pass
     uint32_t pass_samples;    // samples per pixel in this pass
     PathQueue qa, qb;         // qa: paths with a hit record (input of shade); qb: paths to extend
@@ -135,16 +137,25 @@ SPT_DEV void store_path(const PathQueue& q, uint32_t i, const DRay& ray, float l
 }
 
 // ---------------------------------------------------------------------------- primary
+// Blocks are 16x16 pixel tiles of the shard's (rows x width) image.  Tile (tx, ty) appends to
+// queue shard (tx + 9 ty) mod 64: every 8x8 group of tiles touches all 64 shards once, so the
+// shards (and with them the XCDs that later consume them) receive equal shares of any object
+// larger than ~128 px, instead of whole image columns.
+constexpr uint32_t kTile = 16;
+SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % kShards; }
+
 __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
-    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = lp < rc.n_pixels;
-    const uint32_t lpc = valid ? lp : 0u;
-    const uint32_t row_local = lpc / rc.width, i = lpc - row_local * rc.width;
+    const uint32_t tx = blockIdx.x % rc.tiles_x, ty = blockIdx.x / rc.tiles_x;
+    const uint32_t i = tx * kTile + (threadIdx.x % kTile);
+    const uint32_t row_local = ty * kTile + (threadIdx.x / kTile);
+    const bool valid = (i < rc.width) && (row_local < rc.rows);
+    const uint32_t lp = valid ? row_local * rc.width + i : 0u;
     const uint32_t strip = row_local / rc.strip_rows;
     const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
     const uint32_t pixel = j * rc.width + i;
     const bool has_env = sc.env_w != 0u;
-    const uint32_t shard = blockIdx.x % kShards;
+    const bool lazy_rng = rc.sampler == SPT_SAMPLER_RECURRENCE;  // the R2 sampler draws nothing: seed hits only
+    const uint32_t shard = tile_shard(tx, ty);
     f3 sum = mk3(0, 0, 0);
     if (valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
     uint32_t first = rc.pass_samples;
@@ -152,7 +163,8 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     for (uint32_t s = 0; s < rc.pass_samples; ++s) {
         const uint32_t gs = rc.pass_first + s;
         DRng rng;
-        rng.s = spt_rng_seed(rc.seed, pixel, gs);
+        rng.s.state = 0ull;
+        if (!lazy_rng) rng.s = spt_rng_seed(rc.seed, pixel, gs);
         float ox, oy;
         pixel_offset(rc, pixel, gs, rng, &ox, &oy);
         float x = (((float)i + ox) * rc.width_inv - 0.5f) * rc.aspect;           // pt.rs:269
@@ -184,6 +196,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
         }
         uint32_t slot = shard * rc.shard_cap + wave_push(hit, q_count(rc.counts, 0, Q_HIT, shard));
         if (hit) {
+            if (lazy_rng) rng.s = spt_rng_seed(rc.seed, pixel, gs);
             store_path(rc.qa, slot, ray, 0.0f, gray(1.0f), (uint32_t)ri, mk3(0, 0, 0), pack_meta(0u, -1), rng);
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
             rc.hits.inst[slot] = h.inst;
@@ -205,6 +218,11 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // ---------------------------------------------------------------------------- shade
 // One iteration of the `while curr_depth < max_depth` loop of trace_ray, minus the
 // two traversals, for the path vertex in qa[idx] / hits[idx].
+// kSimple is a scene-feature specialisation chosen on the host (spt_scene_create): Lambert
+// materials, delta lights, no emission, no environment, no media.  The general code path is
+// identical arithmetic; the specialisation only removes branches that cannot be taken, which
+// cuts the kernel from 226 to far fewer VGPRs (more waves per SIMD to hide queue latency).
+template <bool kSimple>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
@@ -252,7 +270,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 it = reconstruct_hit(sc, in, ray, h);
             }
 
-            if (medium >= 0) {  // pt.rs:56-96
+            if (!kSimple && medium >= 0) {  // pt.rs:56-96
                 const spt_medium& md = sc.mediums[medium];
                 f3 sigma_t = mk3(md.sigma_t);
                 f3 wo = -ray.d;
@@ -268,7 +286,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     // still in the medium: in-scattering from one light sample
                     lsi = pi;
                     DLightSample ls;
-                    if (sample_light(sc, lsi, rng, &ls)) {
+                    if (sample_light<false>(sc, lsi, rng, &ls)) {
                         float phase = henyey_greenstein(md.g, dot(wo, ls.dir));
                         // shadow_ray_from_medium (pt.rs:212-233): probe the last-hit basic primitive
                         // with the world-space ray, in its own object space
@@ -326,7 +344,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             }
 
             if (!scattered && medium < 0) {
-                if (!does_hit) {  // pt.rs:97-111 (only reached here after leaving a medium)
+                if (!kSimple && !does_hit) {  // pt.rs:97-111 (only reached here after leaving a medium)
                     if (sc.env_w != 0u) {
                         f3 env;
                         float env_pdf;
@@ -340,10 +358,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     const spt_surface& sf = sc.surfaces[it.surface];
                     const uint32_t sflags = sf.flags;
                     DMat mt = load_material(sc, sf.material);
+                    if (kSimple) mt.bxdf = SPT_BXDF_LAMBERT;
                     DCoord coord = surface_coord(sflags, ray, it);
                     f3 po = it.position;
                     f3 le = mk3(sf.emissive);
-                    if (luminance(le) > 0.0f) {
+                    if (!kSimple && luminance(le) > 0.0f) {
                         float weight = 1.0f;
                         if (depth != 0u) weight = power_heuristic(last_pdf, pdf_shape_light(sc, in, sflags, lsi, it, h.prim));
                         rad_add(rc, slot, (thr * le) * weight);
@@ -353,7 +372,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     lsi = po;
                     if (!mat_is_delta(mt)) {
                         DLightSample ls;
-                        if (sample_light(sc, lsi, rng, &ls)) {
+                        if (sample_light<kSimple>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
                             f3 f = mat_eval(mt, wo, wi);
                             float mpdf = mat_pdf(mt, wo, wi);
@@ -380,7 +399,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     thr = thr * crcp(samp.f * spt_abs(samp.wi.z), spt_max(samp.pdf, 0.00001f));
                     float hd = dot(wi_world, coord.hemi);  // Coordinate::in_expected_hemisphere
                     if (!(samp.transmit ? (hd <= 0.0f) : (hd >= 0.0f))) alive = false;
-                    if (alive && dot(wi_world, it.normal) < 0.0f)
+                    if (!kSimple && alive && dot(wi_world, it.normal) < 0.0f)
                         medium = (sflags & SPT_SURF_DOUBLE_SIDED) ? -1 : sf.inside_medium;  // Surface::inside_medium
                     scattered = true;
                 }
@@ -512,4 +531,27 @@ __global__ void __launch_bounds__(256) k_trace_any(DScene sc, uint32_t n, const 
     DRay r;
     r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
     occluded[i] = trace_any(sc, r, rays[i].t_max) ? 1 : 0;
+}
+
+__global__ void k_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b[i], r;
+    switch (fn) {
+    case 0: r = spt_sin(x); break;
+    case 1: r = spt_cos(x); break;
+    case 2: r = spt_log(x); break;
+    case 3: r = spt_exp(x); break;
+    case 4: r = spt_acos(x); break;
+    case 5: r = spt_atan2(x, y); break;
+    case 6: r = spt_asin(x); break;
+    case 7: r = spt_round(x); break;
+    case 8: r = spt_floor(x); break;
+    case 9: r = spt_sqrt(x); break;
+    case 10: r = x / y; break;
+    case 11: r = spt_max(x, y); break;
+    case 12: r = spt_min(x, y); break;
+    default: r = 0.0f; break;
+    }
+    out[i] = r;
 }

@@ -557,8 +557,13 @@ SPT_DEV float instance_pdf(const DScene& sc, const DInstance& in, const DInter& 
     return prim_pdf * original_area / transformed_area;
 }
 
+// kDeltaOnly: the scene has only directional / point / spot lights (checked on the host), so the
+// area-light and environment branches are not even compiled into the kernel.
+template <bool kDeltaOnly>
 SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRng& rng, DLightSample* out) {
-    switch (l.type) {
+    uint32_t type = l.type;
+    if (kDeltaOnly && type > SPT_LIGHT_SPOT) type = SPT_LIGHT_DIRECTIONAL;
+    switch (type) {
     case SPT_LIGHT_DIRECTIONAL:  // directional.rs:26-29
         out->dir = -mk3(l.dir); out->pdf = 1.0f; out->strength = mk3(l.strength); out->dist = SPT_F32_MAX; out->is_delta = true;
         return;
@@ -579,6 +584,7 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
         return;
     }
     case SPT_LIGHT_SHAPE: {  // shape_light.rs:20-42
+        if (kDeltaOnly) return;
         DInstance in = load_instance(sc, l.instance);
         const spt_surface& sf = sc.surfaces[in.surface];
         f3 spos, snrm;
@@ -600,6 +606,7 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
         return;
     }
     default: {  // environment.rs:110-126
+        if (kDeltaOnly) return;
         float pr;
         uint32_t ind = alias_sample(sc.env_props, sc.env_u, sc.env_k, sc.env_w * sc.env_h, rng.next(), &pr);
         uint32_t x = ind % sc.env_w, y = ind / sc.env_w;
@@ -618,18 +625,19 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
 }
 
 // sample_light (uniform.rs:28-41, power_is.rs:49-59); false if the scene has no light
+template <bool kDeltaOnly>
 SPT_DEV bool sample_light(const DScene& sc, f3 position, DRng& rng, DLightSample* out) {
     if (sc.n_lights == 0) return false;
     if (sc.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) {
         float pr;
         uint32_t index = alias_sample(sc.light_props, sc.light_u, sc.light_k, sc.n_lights, rng.next(), &pr);
-        light_sample(sc, sc.lights[index], position, rng, out);
+        light_sample<kDeltaOnly>(sc, sc.lights[index], position, rng, out);
         out->pdf = pr * out->pdf;
     } else {
         float fi = rng.next() * (float)sc.n_lights;
         uint32_t index = spt_f2u_sat(fi);
         if (index > sc.n_lights - 1) index = sc.n_lights - 1;
-        light_sample(sc, sc.lights[index], position, rng, out);
+        light_sample<kDeltaOnly>(sc, sc.lights[index], position, rng, out);
         out->pdf = out->pdf * (1.0f / (float)sc.n_lights);
     }
     return true;

@@ -102,7 +102,7 @@ struct spt_scene {
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, sh[3], counts, rad, film, first_slot, out;
     DeviceBuffer trace_in, trace_out;
     std::mutex mu;
-    uint32_t max_depth_alloc = 0;
+    bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<true>)
     std::vector<hipEvent_t> events;
     ~spt_scene() {
         (void)hipSetDevice(device);
@@ -287,6 +287,15 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         d.env_h = s.env.height;
         for (int i = 0; i < 3; ++i) d.env_scale[i] = s.env.scale[i];
         d.stack_cap = cap;
+        bool simple = s.env.width == 0 && s.n_lights > 0;
+        for (uint32_t i = 0; i < s.n_materials; ++i) simple = simple && s.materials[i].bxdf == SPT_BXDF_LAMBERT;
+        for (uint32_t i = 0; i < s.n_lights; ++i) simple = simple && s.lights[i].type <= SPT_LIGHT_SPOT;
+        for (uint32_t i = 0; i < s.n_surfaces; ++i) {
+            const spt_surface& sf = s.surfaces[i];
+            float lum = 0.299f * sf.emissive[0] + 0.587f * sf.emissive[1] + 0.114f * sf.emissive[2];
+            simple = simple && sf.inside_medium < 0 && !(lum > 0.0f);
+        }
+        sc->simple = simple;
         *out = sc;
         return SPT_OK;
     } catch (const AbiError& e) {
@@ -346,10 +355,17 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
         }
         spp_pass = std::min(spp_pass, p.spp);
-        // queue shards: shard s holds what the primary blocks b = s (mod kShards) can emit, which also
-        // bounds every later generation of that shard
-        const uint32_t pix_blocks = (n_pix + kBlock - 1) / kBlock;
-        const uint64_t shard_cap64 = (uint64_t)((pix_blocks + kShards - 1) / kShards) * kBlock * spp_pass;
+        // queue shards: shard s holds what the primary tiles mapped to it can emit, which also bounds
+        // every later generation of that shard
+        const uint32_t tiles_x = (p.width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
+        const uint32_t pix_blocks = tiles_x * tiles_y;
+        uint32_t max_tiles = 0;
+        {
+            std::vector<uint32_t> per(kShards, 0u);
+            for (uint32_t ty = 0; ty < tiles_y; ++ty)
+                for (uint32_t tx = 0; tx < tiles_x; ++tx) max_tiles = std::max(max_tiles, ++per[(tx + 9u * ty) % kShards]);
+        }
+        const uint64_t shard_cap64 = (uint64_t)max_tiles * kBlock * spp_pass;
         const uint64_t cap64 = shard_cap64 * kShards;
         if (cap64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: pass too large (lower samples_per_pass)");
         const size_t cap = (size_t)cap64;
@@ -380,6 +396,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         rc.seed = p.seed;
         rc.shard_index = p.shard_index; rc.shard_count = shard_count; rc.strip_rows = strip_rows;
         rc.n_pixels = n_pix;
+        rc.rows = rows;
+        rc.tiles_x = tiles_x;
         rc.qa = PathQueue{sc->qa[0].as<float4>(), sc->qa[1].as<float4>(), sc->qa[2].as<float4>(), sc->qa[3].as<float4>(), sc->qa[4].as<uint2>()};
         rc.qb = PathQueue{sc->qb[0].as<float4>(), sc->qb[1].as<float4>(), sc->qb[2].as<float4>(), sc->qb[3].as<float4>(), sc->qb[4].as<uint2>()};
         rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
@@ -433,7 +451,10 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             end();
             for (uint32_t b = 0; b < p.max_depth; ++b) {
                 begin(SPT_K_SHADE);
-                hipLaunchKernelGGL(k_shade, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                if (sc->simple)
+                    hipLaunchKernelGGL(k_shade<true>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                else
+                    hipLaunchKernelGGL(k_shade<false>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
                 end();
                 begin(SPT_K_SHADOW);
                 hipLaunchKernelGGL(k_shadow, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
@@ -516,6 +537,30 @@ static spt_status trace_common(const spt_scene* scene_c, uint32_t n, const spt_r
         HIP_CHECK(hipStreamSynchronize(st));
         return SPT_OK;
     } catch (const AbiError& e) {
+        g_error = e.msg;
+        return e.code;
+    }
+}
+
+spt_status spt_debug_detmath(int32_t device, uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {
+    if (n && (!a || !b || !out)) { g_error = "debug_detmath: null argument"; return SPT_ERR_INVALID_ARG; }
+    if (n == 0) return SPT_OK;
+    DeviceBuffer da, db, dout;
+    try {
+        int nd = usable_device_count();
+        if (nd <= 0) fail(SPT_ERR_NO_DEVICE, "no HIP device is visible: libspt_hip has no CPU fallback");
+        if (device < 0 || device >= nd) fail(SPT_ERR_NO_DEVICE, "device index out of range");
+        HIP_CHECK(hipSetDevice(device));
+        da.upload(a, n);
+        db.upload(b, n);
+        dout.alloc((size_t)n * sizeof(float));
+        hipLaunchKernelGGL(k_detmath, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, fn, n, da.as<float>(), db.as<float>(), dout.as<float>());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        da.release(); db.release(); dout.release();
+        return SPT_OK;
+    } catch (const AbiError& e) {
+        da.release(); db.release(); dout.release();
         g_error = e.msg;
         return e.code;
     }
