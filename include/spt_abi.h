@@ -278,6 +278,12 @@ spt_status spt_shard_rows(const spt_render_params* params, uint32_t* rows);
 spt_status spt_trace_closest(const spt_scene* scene, uint32_t n, const spt_ray* rays, spt_hit* hits);
 spt_status spt_trace_any(const spt_scene* scene, uint32_t n, const spt_ray* rays, uint8_t* occluded);
 
+/* Page-locked host memory for rgb_mean_out: lets the final device-to-host copy of the film run as one
+ * DMA at PCIe rate instead of being staged through the runtime's bounce buffers.  Optional: any host
+ * pointer is accepted by spt_render. */
+spt_status spt_alloc_pinned(uint64_t bytes, void** out);
+void spt_free_pinned(void* p);
+
 /* Test seam: evaluates one function of include/spt_detmath.h on the device (fn: 0 sin, 1 cos,
  * 2 log, 3 exp, 4 acos, 5 atan2(a,b), 6 asin, 7 round, 8 floor, 9 sqrt, 10 a/b, 11 max(a,b),
  * 12 min(a,b)), so the tests can check gfx950 returns the same bits as x86-64. */

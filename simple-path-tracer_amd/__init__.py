@@ -201,6 +201,9 @@ def hip_lib() -> C.CDLL:
         lib.spt_shard_rows.argtypes = [C.POINTER(RenderParams), C.POINTER(C.c_uint32)]
         lib.spt_trace_closest.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.spt_trace_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.spt_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+        lib.spt_free_pinned.argtypes = [C.c_void_p]
+        lib.spt_free_pinned.restype = None
         lib.spt_debug_detmath.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip_lib = lib
     return _hip_lib
@@ -285,8 +288,20 @@ class DeviceScene:
         self._h = C.c_void_p()
         self.scene = scene
         self.device = device
+        self._pinned = {}
         desc = scene.desc
         _check_hip(hip_lib().spt_scene_create(C.byref(desc), device, C.byref(self._h)))
+
+    def film_buffer(self, rows: int, width: int) -> np.ndarray:
+        """Reusable page-locked (rows, width, 3) f32 output buffer (spt_alloc_pinned)."""
+        key = (rows, width)
+        if key not in self._pinned:
+            nbytes = max(rows * width * 3 * 4, 4)
+            ptr = C.c_void_p()
+            _check_hip(hip_lib().spt_alloc_pinned(nbytes, C.byref(ptr)))
+            buf = (C.c_float * (rows * width * 3)).from_address(ptr.value)
+            self._pinned[key] = (ptr, np.ctypeslib.as_array(buf).reshape(rows, width, 3))
+        return self._pinned[key][1]
 
     def trace_closest(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
@@ -301,6 +316,9 @@ class DeviceScene:
         return occ
 
     def close(self) -> None:
+        for ptr, _ in self._pinned.values():
+            hip_lib().spt_free_pinned(ptr)
+        self._pinned.clear()
         if self._h:
             hip_lib().spt_scene_destroy(self._h)
             self._h = C.c_void_p()
@@ -357,15 +375,20 @@ class PathTracer:
 
     def render_shard(self, scene: Scene, config: OutputConfig, device: int = 0, shard_index: int = 0,
                      shard_count: int = 1, strip_rows: int = 16, samples_per_pass: int = 0,
-                     profile: bool = False) -> np.ndarray:
-        """Mean radiance of this shard's rows, shape (rows, width, 3) f32, via the HIP path."""
+                     profile: bool = False, reuse_output: bool = False) -> np.ndarray:
+        """Mean radiance of this shard's rows, shape (rows, width, 3) f32, via the HIP path.
+        reuse_output=True returns a page-locked buffer owned by the device scene that the next call
+        with the same shape overwrites (no per-call allocation, DMA-speed copy-out)."""
         ds = scene.device_scene(device)
         cam = scene.get_camera(config.used_camera_name)
         p = self.params(config.width, config.height, shard_index, shard_count, strip_rows, samples_per_pass,
                         RENDER_PROFILE if profile else 0)
         rows = C.c_uint32()
         _check_hip(hip_lib().spt_shard_rows(C.byref(p), C.byref(rows)))
-        out = np.zeros((rows.value, config.width, 3), dtype=np.float32)
+        if reuse_output and rows.value:
+            out = ds.film_buffer(rows.value, config.width)
+        else:
+            out = np.zeros((rows.value, config.width, 3), dtype=np.float32)
         stats = RenderStats()
         _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(stats)))
         self.last_stats = stats

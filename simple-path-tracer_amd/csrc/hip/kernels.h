@@ -72,6 +72,10 @@ struct RenderCtx {
     float* film;              // n_pixels * 3 running sums
     uint32_t* first_slot;     // per pixel: first sample of the pass that uses a rad slot
     float aspect, width_inv, height_inv, spp_inv;
+    // conservative bounding sphere of all instances relative to the camera eye (primary early-out)
+    f3 bs_oc;                 // sphere centre - eye
+    float bs_c;               // |oc|^2 - R^2   (R inflated by 0.1 %)
+    uint32_t bs_valid;
 };
 
 SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -169,10 +173,24 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
         pixel_offset(rc, pixel, gs, rng, &ox, &oy);
         float x = (((float)i + ox) * rc.width_inv - 0.5f) * rc.aspect;           // pt.rs:269
         float y = ((float)(rc.height - j - 1u) + oy) * rc.height_inv - 0.5f;       // pt.rs:270-271
-        DRay ray = camera_ray(rc.cam, x, y);
+        // PerspectiveCamera::generate_ray (camera/perspective.rs:40-47), split so that a sample whose
+        // un-normalised direction already misses the bounding sphere of the whole scene skips the
+        // normalisation and the traversal: nothing can be hit, and without an environment the sample
+        // is black.  The sphere is inflated, so the test only removes rays every box test would reject.
+        const f3 du = (rc.cam.forward * rc.cam.half_cot + rc.cam.right * x) + rc.cam.up * y;
+        bool may_hit = valid;
+        if (rc.bs_valid && rc.bs_c > 0.0f) {
+            const float b = dot(du, rc.bs_oc);
+            may_hit = valid && (b > 0.0f) && (b * b >= dot(du, du) * rc.bs_c);
+        }
+        DRay ray;
+        ray.o = rc.cam.eye;
+        ray.t_min = kTMinEps;
+        ray.d = du;
+        if (may_hit || has_env) ray.d = normalize(du);
         DHit h;
         h.inst = -1;
-        if (valid) h = trace_closest(sc, ray, SPT_F32_MAX);
+        if (may_hit) h = trace_closest(sc, ray, SPT_F32_MAX);
         const bool hit = valid && h.inst >= 0;
         const size_t ri = (size_t)s * rc.n_pixels + lp;
         if (valid && !hit) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -102,6 +103,8 @@ struct spt_scene {
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, sh[3], counts, rad, film, first_slot, out;
     DeviceBuffer trace_in, trace_out;
     std::mutex mu;
+    double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
+    bool bs_valid = false;
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<true>)
     std::vector<hipEvent_t> events;
     ~spt_scene() {
@@ -296,6 +299,23 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             simple = simple && sf.inside_medium < 0 && !(lum > 0.0f);
         }
         sc->simple = simple;
+        if (s.n_instances) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool finite = true;
+            for (uint32_t i = 0; i < s.n_instances; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = std::min(lo[k], (double)s.instances[i].bmin[k]);
+                    hi[k] = std::max(hi[k], (double)s.instances[i].bmax[k]);
+                    finite = finite && std::isfinite(s.instances[i].bmin[k]) && std::isfinite(s.instances[i].bmax[k]);
+                }
+            double r2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                sc->bs_center[k] = 0.5 * (lo[k] + hi[k]);
+                r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]);
+            }
+            sc->bs_radius = std::sqrt(r2) * 1.001 + 1e-4;
+            sc->bs_valid = finite && std::isfinite(sc->bs_radius) && sc->bs_radius < 1e18;
+        }
         *out = sc;
         return SPT_OK;
     } catch (const AbiError& e) {
@@ -351,7 +371,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         // samples per pass: keep the queues around a few million entries
         uint32_t spp_pass = p.samples_per_pass;
         if (spp_pass == 0) {
-            const uint64_t target = 32ull << 20;
+            const uint64_t target = 64ull << 20;
             spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
         }
         spp_pass = std::min(spp_pass, p.spp);
@@ -411,6 +431,14 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         rc.width_inv = 1.0f / (float)p.width;           // pt.rs:250-251
         rc.height_inv = 1.0f / (float)p.height;
         rc.spp_inv = 1.0f / (float)p.spp;
+        {
+            double oc[3], d2 = 0;
+            for (int k = 0; k < 3; ++k) { oc[k] = sc->bs_center[k] - (double)cam->eye[k]; d2 += oc[k] * oc[k]; }
+            rc.bs_oc = f3{(float)oc[0], (float)oc[1], (float)oc[2]};
+            // a little extra slack for the f32 rounding of oc and of the test itself
+            rc.bs_c = (float)((d2 - sc->bs_radius * sc->bs_radius) * (1.0 - 1e-5));
+            rc.bs_valid = sc->bs_valid ? 1u : 0u;
+        }
 
         hipStream_t st = sc->stream;
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
@@ -540,6 +568,18 @@ static spt_status trace_common(const spt_scene* scene_c, uint32_t n, const spt_r
         g_error = e.msg;
         return e.code;
     }
+}
+
+spt_status spt_alloc_pinned(uint64_t bytes, void** out) {
+    if (!out || bytes == 0) { g_error = "alloc_pinned: bad argument"; return SPT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (usable_device_count() <= 0) { g_error = "no HIP device is visible: libspt_hip has no CPU fallback"; return SPT_ERR_NO_DEVICE; }
+    hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { g_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); return SPT_ERR_OUT_OF_MEMORY; }
+    return SPT_OK;
+}
+void spt_free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 spt_status spt_debug_detmath(int32_t device, uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {
