@@ -148,7 +148,9 @@ SPT_DEV void store_path(const PathQueue& q, uint32_t i, const DRay& ray, float l
 constexpr uint32_t kTile = 16;
 SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % kShards; }
 
+template <bool kLds>
 __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
+    stage_geometry<kLds>(sc);
     const uint32_t tx = blockIdx.x % rc.tiles_x, ty = blockIdx.x / rc.tiles_x;
     const uint32_t i = tx * kTile + (threadIdx.x % kTile);
     const uint32_t row_local = ty * kTile + (threadIdx.x / kTile);
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
         if (may_hit || has_env) ray.d = normalize(du);
         DHit h;
         h.inst = -1;
-        if (may_hit) h = trace_closest(sc, ray, SPT_F32_MAX);
+        if (may_hit) h = trace_closest<kLds>(sc, ray, SPT_F32_MAX);
         const bool hit = valid && h.inst >= 0;
         const size_t ri = (size_t)s * rc.n_pixels + lp;
         if (valid && !hit) {
@@ -450,7 +452,9 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
 }
 
 // ---------------------------------------------------------------------------- shadow
+template <bool kLds>
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
+    stage_geometry<kLds>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
     const uint32_t qbase = shard * rc.shard_cap;
@@ -460,12 +464,14 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_
         float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx], c = rc.shadow.contrib_slot[idx];
         DRay r;
         r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-        if (!trace_any(sc, r, b.w)) rad_add(rc, __float_as_uint(c.w), mk3(c));
+        if (!trace_any<kLds>(sc, r, b.w)) rad_add(rc, __float_as_uint(c.w), mk3(c));
     }
 }
 
 // ---------------------------------------------------------------------------- extend
+template <bool kLds>
 __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
+    stage_geometry<kLds>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
     uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
@@ -484,7 +490,7 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
             rs = rc.qb.rng[idx];
             DRay r;
             r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-            h = trace_closest(sc, r, SPT_F32_MAX);
+            h = trace_closest<kLds>(sc, r, SPT_F32_MAX);
             const uint32_t meta = __float_as_uint(d.w);
             const bool in_medium = (meta >> 8) != 0u;
             if (h.inst >= 0 || in_medium) {
@@ -530,12 +536,14 @@ __global__ void __launch_bounds__(256) k_finish(RenderCtx rc, float* out) {
 }
 
 // ---------------------------------------------------------------------------- test seams
+template <bool kLds>
 __global__ void __launch_bounds__(256) k_trace_closest(DScene sc, uint32_t n, const spt_ray* rays, spt_hit* hits) {
+    stage_geometry<kLds>(sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DRay r;
     r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
-    DHit h = trace_closest(sc, r, rays[i].t_max);
+    DHit h = trace_closest<kLds>(sc, r, rays[i].t_max);
     const bool hit = h.inst >= 0;
     hits[i].t = hit ? h.t : SPT_F32_MAX;
     hits[i].instance = h.inst;
@@ -543,12 +551,14 @@ __global__ void __launch_bounds__(256) k_trace_closest(DScene sc, uint32_t n, co
     hits[i].v = hit ? h.v : 0.0f;
     hits[i].w = hit ? h.w : 0.0f;
 }
+template <bool kLds>
 __global__ void __launch_bounds__(256) k_trace_any(DScene sc, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
+    stage_geometry<kLds>(sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DRay r;
     r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
-    occluded[i] = trace_any(sc, r, rays[i].t_max) ? 1 : 0;
+    occluded[i] = trace_any<kLds>(sc, r, rays[i].t_max) ? 1 : 0;
 }
 
 __global__ void k_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {

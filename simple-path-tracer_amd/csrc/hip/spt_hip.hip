@@ -98,7 +98,9 @@ struct spt_scene {
     hipStream_t stream = nullptr;
     DScene d{};
     DeviceBuffer tlas, blas, tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
-    DeviceBuffer light_props, light_u, light_k, env_texels, env_props, env_u, env_k;
+    DeviceBuffer light_props, light_u, light_k, env_texels, env_props, env_u, env_k, geo;
+    bool lds_geo = false;   // traversal geometry small enough to live in LDS (k_*<true>)
+    size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, sh[3], counts, rad, film, first_slot, out;
     DeviceBuffer trace_in, trace_out;
@@ -290,6 +292,31 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         d.env_h = s.env.height;
         for (int i = 0; i < 3; ++i) d.env_scale[i] = s.env.scale[i];
         d.stack_cap = cap;
+        {
+            // one float4 blob for everything the traversal touches
+            std::vector<float4> blob;
+            auto append = [&](const void* src, size_t bytes) {
+                uint32_t off = (uint32_t)blob.size();
+                size_t n4 = (bytes + 15) / 16;
+                blob.resize(blob.size() + n4, make_float4(0, 0, 0, 0));
+                if (bytes) std::memcpy(&blob[off], src, bytes);
+                return off;
+            };
+            d.o_tlas = append(s.tlas_nodes, (size_t)s.n_tlas_nodes * sizeof(spt_bvh_node));
+            d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
+            d.o_mesh = append(s.meshes, (size_t)s.n_meshes * sizeof(spt_mesh));
+            d.o_blas = append(s.blas_nodes, (size_t)s.n_blas_nodes * sizeof(spt_bvh_node));
+            d.o_tri = append(s.tri_pos, (size_t)s.n_tris * sizeof(spt_tri_pos));
+            d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
+            if (blob.size() > 0x7fffffffull / 16) fail(SPT_ERR_UNSUPPORTED, "scene geometry larger than 32 GiB");
+            sc->geo.upload(blob.data(), blob.size());
+            d.geo = sc->geo.as<float4>();
+            d.geo_f4 = (uint32_t)blob.size();
+            const size_t stack_bytes = (size_t)cap * kBlock * sizeof(uint32_t);
+            const size_t geo_bytes = blob.size() * 16;
+            sc->lds_geo = geo_bytes <= 32u * 1024u && stack_bytes + geo_bytes <= 64u * 1024u;
+            sc->lds_bytes = stack_bytes + (sc->lds_geo ? geo_bytes : 0);
+        }
         bool simple = s.env.width == 0 && s.n_lights > 0;
         for (uint32_t i = 0; i < s.n_materials; ++i) simple = simple && s.materials[i].bxdf == SPT_BXDF_LAMBERT;
         for (uint32_t i = 0; i < s.n_lights; ++i) simple = simple && s.lights[i].type <= SPT_LIGHT_SPOT;
@@ -337,7 +364,7 @@ void spt_scene_destroy(spt_scene* scene) {
                            &scene->spheres, &scene->surfaces, &scene->materials, &scene->mediums, &scene->lights,
                            &scene->light_props, &scene->light_u, &scene->light_k, &scene->env_texels, &scene->env_props,
                            &scene->env_u, &scene->env_k, &scene->hit_f4, &scene->hit_inst, &scene->counts, &scene->rad,
-                           &scene->film, &scene->first_slot, &scene->out, &scene->trace_in, &scene->trace_out};
+                           &scene->film, &scene->first_slot, &scene->out, &scene->trace_in, &scene->trace_out, &scene->geo};
     for (auto* b : all) b->release();
     for (auto& b : scene->qa) b.release();
     for (auto& b : scene->qb) b.release();
@@ -442,7 +469,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
 
         hipStream_t st = sc->stream;
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
-        const size_t lds = (size_t)sc->d.stack_cap * kBlock * sizeof(uint32_t);
+        const size_t lds = sc->lds_bytes;
+        const bool L = sc->lds_geo;
         struct Span { int cls; size_t e0; };
         std::vector<Span> spans;
         size_t ev_used = 0;
@@ -475,7 +503,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             HIP_CHECK(hipMemsetAsync(rc.counts, 0, counts_bytes, st));
             end();
             begin(SPT_K_PRIMARY);
-            hipLaunchKernelGGL(k_primary, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+            if (L) hipLaunchKernelGGL(k_primary<true>, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+            else hipLaunchKernelGGL(k_primary<false>, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
             end();
             for (uint32_t b = 0; b < p.max_depth; ++b) {
                 begin(SPT_K_SHADE);
@@ -485,11 +514,13 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     hipLaunchKernelGGL(k_shade<false>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
                 end();
                 begin(SPT_K_SHADOW);
-                hipLaunchKernelGGL(k_shadow, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                 end();
                 if (b + 1 < p.max_depth) {
                     begin(SPT_K_EXTEND);
-                    hipLaunchKernelGGL(k_extend, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                    if (L) hipLaunchKernelGGL(k_extend<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                    else hipLaunchKernelGGL(k_extend<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                     end();
                 }
             }
@@ -554,12 +585,15 @@ static spt_status trace_common(const spt_scene* scene_c, uint32_t n, const spt_r
         sc->trace_out.ensure((size_t)n * out_elem);
         hipStream_t st = sc->stream;
         HIP_CHECK(hipMemcpyAsync(sc->trace_in.p, rays, (size_t)n * sizeof(spt_ray), hipMemcpyHostToDevice, st));
-        const size_t lds = (size_t)sc->d.stack_cap * kBlock * sizeof(uint32_t);
+        const size_t lds = sc->lds_bytes;
         dim3 grid((n + kBlock - 1) / kBlock);
-        if (closest)
-            hipLaunchKernelGGL(k_trace_closest, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
-        else
-            hipLaunchKernelGGL(k_trace_any, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<uint8_t>());
+        if (closest) {
+            if (sc->lds_geo) hipLaunchKernelGGL(k_trace_closest<true>, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
+            else hipLaunchKernelGGL(k_trace_closest<false>, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
+        } else {
+            if (sc->lds_geo) hipLaunchKernelGGL(k_trace_any<true>, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<uint8_t>());
+            else hipLaunchKernelGGL(k_trace_any<false>, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<uint8_t>());
+        }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, sc->trace_out.p, (size_t)n * out_elem, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));

@@ -39,6 +39,12 @@ struct DScene {
     uint32_t env_w, env_h;
     float env_scale[3];
     uint32_t stack_cap;        // LDS stack entries per lane the scene needs
+    // Traversal geometry as ONE float4 blob [tlas | instances | meshes | blas | tri_pos | spheres]
+    // (offsets in float4 units).  Small scenes are staged into LDS once per workgroup
+    // (k_*<true>) and every node / triangle / instance fetch becomes a ds_read_b128.
+    const float4* geo;
+    uint32_t geo_f4;           // blob length in float4
+    uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
 };
 
 struct DHit {
@@ -50,6 +56,23 @@ struct DHit {
 // per-lane stack in LDS: entry `level` of this lane
 extern __shared__ uint32_t spt_lds_stack[];
 SPT_DEV uint32_t& stack_at(uint32_t level) { return spt_lds_stack[level * blockDim.x + threadIdx.x]; }
+
+// geometry fetch: LDS copy (kLds) or the global blob
+SPT_DEV float4* geo_lds(const DScene& sc) { return reinterpret_cast<float4*>(spt_lds_stack + sc.stack_cap * blockDim.x); }
+template <bool kLds>
+SPT_DEV float4 geo_ld(const DScene& sc, uint32_t off) {
+    if (kLds) return geo_lds(sc)[off];
+    return sc.geo[off];
+}
+// once per workgroup, before any traversal
+template <bool kLds>
+SPT_DEV void stage_geometry(const DScene& sc) {
+    if (kLds) {
+        float4* dst = geo_lds(sc);
+        for (uint32_t i = threadIdx.x; i < sc.geo_f4; i += blockDim.x) dst[i] = sc.geo[i];
+        __syncthreads();
+    }
+}
 
 SPT_DEV f3 recip3(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 
@@ -69,8 +92,7 @@ SPT_DEV bool slab_test(float4 lo, float4 hi, f3 o, f3 inv_d, float t_min, float 
 
 // Triangle::intersect_ray (triangle.rs:124-147), branch-free: same values, the
 // nested ifs become one predicate
-SPT_DEV bool tri_test(const float4* tri_pos, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
-    float4 a = tri_pos[3 * tri], b = tri_pos[3 * tri + 1], c = tri_pos[3 * tri + 2];
+SPT_DEV bool tri_test3(float4 a, float4 b, float4 c, const DRay& r, float* t, float* v_out, float* w_out) {
     f3 p0 = mk3(a), p1 = mk3(b), p2 = mk3(c);
     f3 e1 = p1 - p0;
     f3 e2 = p2 - p0;
@@ -88,6 +110,15 @@ SPT_DEV bool tri_test(const float4* tri_pos, uint32_t tri, const DRay& r, float*
     return (det != 0.0f) & (v >= 0.0f) & (w >= 0.0f) & (u >= 0.0f);
 }
 
+SPT_DEV bool tri_test(const float4* tri_pos, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
+    return tri_test3(tri_pos[3 * tri], tri_pos[3 * tri + 1], tri_pos[3 * tri + 2], r, t, v_out, w_out);
+}
+template <bool kLds>
+SPT_DEV bool tri_test_geo(const DScene& sc, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
+    const uint32_t o = sc.o_tri + 3u * tri;
+    return tri_test3(geo_ld<kLds>(sc, o), geo_ld<kLds>(sc, o + 1), geo_ld<kLds>(sc, o + 2), r, t, v_out, w_out);
+}
+
 // Sphere::intersect_ray (sphere.rs:25-39)
 SPT_DEV bool sphere_roots(float4 s, const DRay& r, float* mn, float* mx) {
     f3 oc = r.o - mk3(s);
@@ -101,9 +132,10 @@ SPT_DEV bool sphere_roots(float4 s, const DRay& r, float* mn, float* mx) {
     return delta >= 0.0f;
 }
 
-SPT_DEV DRay to_object(const float4* instances, uint32_t inst, const DRay& r, uint32_t* prim_type, uint32_t* prim_id) {
-    const float4* I = instances + 12 * inst;
-    float4 m0 = I[0], m1 = I[1], m2 = I[2], k = I[8];
+template <bool kLds>
+SPT_DEV DRay to_object(const DScene& sc, uint32_t inst, const DRay& r, uint32_t* prim_type, uint32_t* prim_id) {
+    const uint32_t I = sc.o_inst + 12u * inst;
+    float4 m0 = geo_ld<kLds>(sc, I), m1 = geo_ld<kLds>(sc, I + 1), m2 = geo_ld<kLds>(sc, I + 2), k = geo_ld<kLds>(sc, I + 8);
     float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
     *prim_type = __float_as_uint(k.y);
     *prim_id = __float_as_uint(k.z);
@@ -115,6 +147,7 @@ SPT_DEV DRay to_object(const float4* instances, uint32_t inst, const DRay& r, ui
 }
 
 // Closest hit of the scene aggregate.  `base` = first free stack level.
+template <bool kLds>
 SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
     DHit h;
     h.t = t_max;
@@ -136,7 +169,7 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
             // pop TLAS nodes until a leaf is entered
             if (sp == 0) break;
             uint32_t ni = stack_at(--sp);
-            float4 lo = sc.tlas_nodes[2 * ni], hi = sc.tlas_nodes[2 * ni + 1];
+            float4 lo = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni + 1u);
             if (!slab_test(lo, hi, ray.o, inv_w, ray.t_min, h.t)) continue;
             uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
             if (b & SPT_LEAF_FLAG) {
@@ -150,30 +183,30 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
         }
         uint32_t inst = next_inst++;
         uint32_t prim_type, prim_id;
-        DRay orr = to_object(sc.instances, inst, ray, &prim_type, &prim_id);
+        DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
         if (prim_type == SPT_PRIM_SPHERE) {
             float mn, mx;
-            if (sphere_roots(sc.spheres[prim_id], orr, &mn, &mx)) {
+            if (sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx)) {
                 float t = (mn < orr.t_min) ? mx : mn;  // sphere.rs:61
                 if (orr.t_min < t && t < h.t) {
                     h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)prim_id; h.v = 0.0f; h.w = 0.0f;
                 }
             }
         } else {
-            uint4 mesh = sc.meshes[prim_id];
+            const uint32_t mesh_root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
             f3 inv_o = recip3(orr.d);
             const uint32_t base = sp;
-            stack_at(sp++) = mesh.x;
+            stack_at(sp++) = mesh_root;
             while (sp > base) {
                 uint32_t ni = stack_at(--sp);
-                float4 lo = sc.blas_nodes[2 * ni], hi = sc.blas_nodes[2 * ni + 1];
+                float4 lo = geo_ld<kLds>(sc, sc.o_blas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_blas + 2u * ni + 1u);
                 if (!slab_test(lo, hi, orr.o, inv_o, orr.t_min, h.t)) continue;
                 uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
                 if (b & SPT_LEAF_FLAG) {
                     uint32_t n = b & ~SPT_LEAF_FLAG;
                     for (uint32_t i = a; i < a + n; ++i) {
                         float t, v, w;
-                        bool ok = tri_test(sc.tri_pos, i, orr, &t, &v, &w);
+                        bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
                         if (ok && t > orr.t_min && t < h.t) {  // triangle.rs:187
                             h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)i; h.v = v; h.w = w;
                         }
@@ -189,6 +222,7 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
 }
 
 // Any hit in (t_min, t_max): intersect_test of the aggregate
+template <bool kLds>
 SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
     const bool group = (sc.aggregate == SPT_AGGREGATE_GROUP);
     f3 inv_w = recip3(ray.d);
@@ -203,7 +237,7 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
         if (next_inst == end_inst) {
             if (sp == 0) break;
             uint32_t ni = stack_at(--sp);
-            float4 lo = sc.tlas_nodes[2 * ni], hi = sc.tlas_nodes[2 * ni + 1];
+            float4 lo = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni + 1u);
             if (!slab_test(lo, hi, ray.o, inv_w, ray.t_min, t_max)) continue;
             uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
             if (b & SPT_LEAF_FLAG) {
@@ -217,25 +251,25 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
         }
         uint32_t inst = next_inst++;
         uint32_t prim_type, prim_id;
-        DRay orr = to_object(sc.instances, inst, ray, &prim_type, &prim_id);
+        DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
         if (prim_type == SPT_PRIM_SPHERE) {
             float mn, mx;
-            if (sphere_roots(sc.spheres[prim_id], orr, &mn, &mx) && mn < t_max && mx > orr.t_min) return true;  // sphere.rs:51-56
+            if (sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx) && mn < t_max && mx > orr.t_min) return true;  // sphere.rs:51-56
         } else {
-            uint4 mesh = sc.meshes[prim_id];
+            const uint32_t mesh_root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
             f3 inv_o = recip3(orr.d);
             const uint32_t base = sp;
-            stack_at(sp++) = mesh.x;
+            stack_at(sp++) = mesh_root;
             while (sp > base) {
                 uint32_t ni = stack_at(--sp);
-                float4 lo = sc.blas_nodes[2 * ni], hi = sc.blas_nodes[2 * ni + 1];
+                float4 lo = geo_ld<kLds>(sc, sc.o_blas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_blas + 2u * ni + 1u);
                 if (!slab_test(lo, hi, orr.o, inv_o, orr.t_min, t_max)) continue;
                 uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
                 if (b & SPT_LEAF_FLAG) {
                     uint32_t n = b & ~SPT_LEAF_FLAG;
                     for (uint32_t i = a; i < a + n; ++i) {
                         float t, v, w;
-                        if (tri_test(sc.tri_pos, i, orr, &t, &v, &w) && t > orr.t_min && t < t_max) return true;
+                        if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w) && t > orr.t_min && t < t_max) return true;
                     }
                 } else if (sp + 2 <= sc.stack_cap) {
                     stack_at(sp++) = a;
