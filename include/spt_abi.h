@@ -241,6 +241,8 @@ typedef struct spt_render_stats {
     double gpu_ms;                 /* HIP-event time of the whole call on the render stream */
     double kernel_ms[SPT_N_KERNELS];      /* per kernel class (SPT_RENDER_PROFILE only)     */
     uint32_t kernel_launches[SPT_N_KERNELS];
+    uint64_t primary_hits;         /* camera samples whose primary ray hit something           */
+    uint64_t path_vertices;        /* records consumed by the shade stage over all bounces     */
 } spt_render_stats;
 
 /* Closest-hit record: what BvhAccel/Group::intersect leave in `Intersection`

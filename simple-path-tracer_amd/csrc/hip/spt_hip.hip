@@ -495,7 +495,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         HIP_CHECK(hipEventRecord(ev_total0, st));
         HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
         std::vector<uint32_t> h_counts;
-        uint64_t seg_closest = 0, seg_shadow = 0;
+        uint64_t seg_closest = 0, seg_shadow = 0, primary_hits = 0, path_vertices = 0;
         for (uint32_t s0 = 0; s0 < p.spp; s0 += spp_pass) {
             rc.pass_first = s0;
             rc.pass_samples = std::min(spp_pass, p.spp - s0);
@@ -537,7 +537,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * 3 + q) * kShards + s) * 32];
                     return t;
                 };
+                primary_hits += qsum(0, Q_HIT);
                 for (uint32_t b = 0; b < p.max_depth; ++b) {
+                    path_vertices += qsum(b, Q_HIT);
                     seg_shadow += qsum(b, Q_SHADOW);
                     if (b + 1 < p.max_depth) seg_closest += qsum(b, Q_EXT);
                 }
@@ -554,6 +556,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             stats->samples = (uint64_t)n_pix * p.spp;
             stats->segments_closest = seg_closest;
             stats->segments_shadow = seg_shadow;
+            stats->primary_hits = primary_hits;
+            stats->path_vertices = path_vertices;
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_total0, ev_total1));
             stats->gpu_ms = ms;
