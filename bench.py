@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--backend", default="cpu:gloo,cuda:nccl", help="torch.distributed backend (N > 1)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -95,12 +98,14 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     spt = load_pkg()
     scene = spt.load_scene(args.scene)
@@ -113,7 +118,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if "nccl" in args.backend:
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     kernel_ms = np.zeros(spt.N_KERNELS)
@@ -218,7 +226,7 @@ def main():
             out["config"]["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 
