@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Render one BASELINE config on the GPU, report Msamples/s, and check a row shard of the same
+render against the CPU oracle (per-pixel mean L1 + bit mismatches).  Not part of the product path.
+
+  python tools/run_config.py cfg4 [--width 1024 --height 1024 --spp 512]
+  python tools/run_config.py cfg5 [--width 2048 --height 2048 --spp 64]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "scenes_amd"))
+import _util  # noqa: E402
+
+CONFIGS = {
+    "cfg2": ("scenes_amd/cfg2_cube.json", "scenes_amd/pt.json", None, 1024, 1024, 256),
+    "cfg4": ("scenes_amd/generated/cfg4_materials_env.json", "scenes_amd/generated/pt_random512.json", "main", 1024, 1024, 512),
+    "cfg5": ("scenes_amd/generated/cfg5_blob_medium.json", "scenes_amd/generated/pt_recurrence512.json", "main", 2048, 2048, 512),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=sorted(CONFIGS))
+    ap.add_argument("--width", type=int)
+    ap.add_argument("--height", type=int)
+    ap.add_argument("--spp", type=int)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--check-rows", type=int, default=8, help="image rows compared against the oracle")
+    ap.add_argument("--check-spp", type=int, default=0, help="spp of the oracle comparison (0 = same as --spp)")
+    ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    scene_p, rend_p, cam, w, h, spp = CONFIGS[args.config]
+    w, h, spp = args.width or w, args.height or h, args.spp or spp
+    if "generated" in scene_p and not os.path.exists(os.path.join(ROOT, scene_p)):
+        import make_scenes
+        make_scenes.main()
+        make_scenes.make_full()
+    spt = _util.load_pkg()
+    _util.ensure_cpu_build()
+    t0 = time.perf_counter()
+    scene = spt.load_scene(os.path.join(ROOT, scene_p))
+    t_load = time.perf_counter() - t0
+    r = spt.load_renderer(os.path.join(ROOT, rend_p), seed=1)
+    if r.sampler != spt.SAMPLER_JITTERED:
+        r.spp = spp
+    cfg = spt.OutputConfig(w, h, None, cam)
+    t0 = time.perf_counter()
+    scene.device_scene(0)
+    t_up = time.perf_counter() - t0
+    film = r.render_shard(scene, cfg, samples_per_pass=args.samples_per_pass, reuse_output=True)  # warm-up
+    best = 1e9
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        film = r.render_shard(scene, cfg, samples_per_pass=args.samples_per_pass, profile=False, reuse_output=True)
+        best = min(best, time.perf_counter() - t0)
+    st = r.last_stats
+    prof = r.render_shard(scene, cfg, samples_per_pass=args.samples_per_pass, profile=True, reuse_output=True)
+    pst = r.last_stats
+    res = {
+        "config": args.config, "width": w, "height": h, "spp": r.spp, "load_s": round(t_load, 2), "upload_s": round(t_up, 2),
+        "Msamples_per_s": round(st.samples / best / 1e6, 1), "ms": round(best * 1e3, 2),
+        "segments_per_sample": round((st.segments_closest + st.segments_shadow) / st.samples, 3),
+        "Mrays_per_s": round((st.segments_closest + st.segments_shadow) / best / 1e6, 1),
+        "kernel_ms": {spt.KERNEL_NAMES[k]: round(pst.kernel_ms[k], 2) for k in range(spt.N_KERNELS)},
+        "film_mean": [round(float(x), 5) for x in film.reshape(-1, 3).mean(0)], "finite": bool(np.isfinite(film).all()),
+    }
+    if args.check_rows:
+        # one shard of `check_rows` rows from the middle of the image, same params, GPU vs oracle
+        strip = args.check_rows
+        count = max(h // strip, 1)
+        index = count // 2
+        rc = spt.PathTracer(r.max_depth, r.sampler, args.check_spp or r.spp, r.division_x, r.division_y, r.filter_radius, r.seed)
+        g = rc.render_shard(scene, cfg, shard_index=index, shard_count=count, strip_rows=strip).copy()
+        t0 = time.perf_counter()
+        o, ost = _util.oracle_render(scene, rc, w, h, camera=cam, flags=_util.ORACLE_SLAB_RECIPROCAL, shard_index=index,
+                                     shard_count=count, strip_rows=strip)
+        dt = time.perf_counter() - t0
+        res["check"] = {"rows": int(g.shape[0]), "spp": rc.spp, "mean_L1": float(np.abs(g - o).mean()),
+                        "words_differ": int((g.view(np.uint32) != o.view(np.uint32)).sum()), "words": int(g.size),
+                        "oracle_Msamples_per_s": round(ost.samples / dt / 1e6, 3), "oracle_threads": ost.threads,
+                        "oracle_nodes_per_segment": round(ost.node_tests / max(ost.segments_closest + ost.segments_shadow, 1), 2),
+                        "oracle_tris_per_segment": round(ost.tri_tests / max(ost.segments_closest + ost.segments_shadow, 1), 2)}
+    if args.out:
+        spt.write_png(args.out, film)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
