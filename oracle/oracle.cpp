@@ -90,7 +90,7 @@ inline float avg(Color c) { return (c.r + c.g + c.b) / 3.0f; }
 inline bool is_finite(Color c) { return spt_is_finite(c.r) && spt_is_finite(c.g) && spt_is_finite(c.b); }
 
 struct Flags {
-    bool slab_recip, brute, libm;
+    bool slab_recip, brute, libm, tie_min_id;
 };
 
 struct Math {  // D2: deterministic kernels by default, libm on request
@@ -138,6 +138,7 @@ struct Inter {
     int32_t prim = -1;       // BasicPrimitiveRef: triangle (absolute) or sphere index
     int32_t prim_type = -1;  // SPT_PRIM_*
     float bv = 0, bw = 0;    // barycentrics of the accepted triangle hit
+    int32_t cand_instance = -1;  // instance being traversed (for the ORACLE_TIE_MIN_ID rule)
 };
 
 struct Counters {
@@ -152,7 +153,7 @@ struct Ctx {
 };
 
 // ---------------------------------------------------------------- src/core/bbox.rs:63-93
-inline bool bbox_intersect_test(const Ctx& cx, const spt_bvh_node& n, const Ray& ray, Vec3 inv_d, float t_max) {
+inline bool bbox_intersect_test(const Ctx& cx, const spt_bvh_node& n, const Ray& ray, Vec3 inv_d, float t_max, bool tie_cull = false) {
     cx.c->nodes++;
     if (n.bmin[0] > n.bmax[0] || n.bmin[1] > n.bmax[1] || n.bmin[2] > n.bmax[2]) return false;  // is_empty
     float x0, x1, y0, y1, z0, z1;
@@ -171,7 +172,7 @@ inline bool bbox_intersect_test(const Ctx& cx, const spt_bvh_node& n, const Ray&
     float t0 = spt_max(xa, spt_max(ya, za));
     float t1 = spt_min(xb, spt_min(yb, zb));
     if (!(t0 <= t1)) return false;
-    return t1 > ray.t_min && t0 < t_max;
+    return t1 > ray.t_min && (tie_cull ? t0 <= t_max : t0 < t_max);
 }
 inline Vec3 recip_dir(const Ray& r) { return v3(1.0f / r.direction.x, 1.0f / r.direction.y, 1.0f / r.direction.z); }
 
@@ -202,11 +203,20 @@ inline bool triangle_intersect_ray(const Ctx& cx, const spt_tri_pos& tp, const R
     return false;
 }
 
+// acceptance of a candidate at distance t: the reference's `t < inter.t`, or the order-independent
+// (t, instance, prim) minimum under ORACLE_TIE_MIN_ID
+inline bool closer(const Ctx& cx, float t, int32_t prim, const Inter& inter) {
+    if (t < inter.t) return true;
+    if (!cx.f.tie_min_id || t != inter.t || inter.instance < 0) return false;
+    if (inter.cand_instance != inter.instance) return inter.cand_instance < inter.instance;
+    return prim < inter.prim;
+}
+
 // triangle.rs:176-218: accept + interpolate (object space)
 inline bool triangle_intersect(const Ctx& cx, uint32_t tri, const Ray& ray, Inter& inter) {
     float t, v, w;
     if (triangle_intersect_ray(cx, cx.d->tri_pos[tri], ray, &t, &v, &w)) {
-        if (t > ray.t_min && t < inter.t) {
+        if (t > ray.t_min && closer(cx, t, (int32_t)tri, inter)) {
             float u = 1.0f - v - w;
             const spt_tri_attr& a = cx.d->tri_attr[tri];
             inter.t = t;
@@ -214,6 +224,7 @@ inline bool triangle_intersect(const Ctx& cx, uint32_t tri, const Ray& ray, Inte
             inter.tangent = (v3(a.t[0]) * u + v3(a.t[1]) * v) + v3(a.t[2]) * w;
             inter.bitangent = (v3(a.b[0]) * u + v3(a.b[1]) * v) + v3(a.b[2]) * w;
             inter.prim = (int32_t)tri;
+            inter.instance = inter.cand_instance;
             inter.prim_type = SPT_PRIM_MESH;
             inter.bv = v;
             inter.bw = w;
@@ -266,8 +277,9 @@ inline bool sphere_intersect(const Ctx& cx, uint32_t si, const Ray& ray, Inter& 
     float mn, mx;
     if (sphere_intersect_ray(cx, s, ray, &mn, &mx)) {
         float t = (mn < ray.t_min) ? mx : mn;
-        if (ray.t_min < t && t < inter.t) {
+        if (ray.t_min < t && closer(cx, t, (int32_t)si, inter)) {
             inter.t = t;
+            inter.instance = inter.cand_instance;
             Vec3 norm = (point_at(ray, t) - v3(s.center)) / s.radius;
             inter.normal = norm;
             sphere_frame(norm, &inter.tangent, &inter.bitangent);
@@ -300,7 +312,7 @@ inline bool blas_intersect(const Ctx& cx, const spt_mesh& mesh, const Ray& ray, 
     stack[sp++] = mesh.root;
     while (sp > 0) {
         const spt_bvh_node& u = cx.d->blas_nodes[stack[--sp]];
-        if (!bbox_intersect_test(cx, u, ray, inv_d, inter.t)) continue;
+        if (!bbox_intersect_test(cx, u, ray, inv_d, inter.t, cx.f.tie_min_id)) continue;
         if (u.b & SPT_LEAF_FLAG) {
             uint32_t n = u.b & ~SPT_LEAF_FLAG;
             for (uint32_t i = u.a; i < u.a + n; ++i) result |= triangle_intersect(cx, i, ray, inter);
@@ -344,6 +356,7 @@ inline bool instance_intersect(const Ctx& cx, uint32_t ii, const Ray& ray, Inter
     cx.c->insts++;
     const spt_instance& in = cx.d->instances[ii];
     Ray tr = transformed_by(ray, in.inv);
+    inter.cand_instance = (int32_t)ii;
     bool hit = (in.prim_type == SPT_PRIM_SPHERE) ? sphere_intersect(cx, in.prim_id, tr, inter)
                                                  : blas_intersect(cx, cx.d->meshes[in.prim_id], tr, inter);
     if (hit) {
@@ -380,7 +393,7 @@ bool aggregate_intersect(const Ctx& cx, const Ray& ray, Inter& inter) {
     stack[sp++] = 0;
     while (sp > 0) {
         const spt_bvh_node& u = d.tlas_nodes[stack[--sp]];
-        if (!bbox_intersect_test(cx, u, ray, inv_d, inter.t)) continue;
+        if (!bbox_intersect_test(cx, u, ray, inv_d, inter.t, cx.f.tie_min_id)) continue;
         if (u.b & SPT_LEAF_FLAG) {
             uint32_t n = u.b & ~SPT_LEAF_FLAG;
             for (uint32_t i = u.a; i < u.a + n; ++i) result |= instance_intersect(cx, i, ray, inter);
@@ -1242,7 +1255,7 @@ int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_r
     if (n_threads < 1) n_threads = 1;
     uint32_t nrows = (uint32_t)rows.size();
     if ((uint32_t)n_threads > nrows && nrows > 0) n_threads = (int32_t)nrows;
-    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0};
+    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0, (flags & ORACLE_TIE_MIN_ID) != 0};
     std::vector<Counters> counters((size_t)n_threads);
     const float aspect = (float)p.width / (float)p.height;
     const float width_inv = 1.0f / (float)p.width, height_inv = 1.0f / (float)p.height;
@@ -1290,7 +1303,7 @@ int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_r
 
 int oracle_trace_closest(const spt_scene_desc* desc, uint32_t flags, uint32_t n, const spt_ray* rays, spt_hit* hits) {
     if (!desc || (!rays && n) || (!hits && n)) return 1;
-    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0};
+    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0, (flags & ORACLE_TIE_MIN_ID) != 0};
     Counters c;
     Ctx cx{desc, f, Math{f.libm}, &c};
     for (uint32_t i = 0; i < n; ++i) {
@@ -1309,7 +1322,7 @@ int oracle_trace_closest(const spt_scene_desc* desc, uint32_t flags, uint32_t n,
 
 int oracle_trace_any(const spt_scene_desc* desc, uint32_t flags, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
     if (!desc || (!rays && n) || (!occluded && n)) return 1;
-    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0};
+    Flags f{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0, (flags & ORACLE_TIE_MIN_ID) != 0};
     Counters c;
     Ctx cx{desc, f, Math{f.libm}, &c};
     for (uint32_t i = 0; i < n; ++i) {
@@ -1340,7 +1353,7 @@ float oracle_hg_cdf_inverse(float g, float r) { return henyey_greenstein_cdf_inv
 uint32_t oracle_alias_sample(const spt_alias_table* a, float rand, float* prob) { return alias_sample(*a, rand, prob); }
 void oracle_env_lookup(const spt_scene_desc* d, const float wi[3], float rgb[3], float* pdf) {
     Counters c;
-    Ctx cx{d, Flags{false, false, false}, Math{false}, &c};
+    Ctx cx{d, Flags{false, false, false, false}, Math{false}, &c};
     Color col_;
     env_strength_pdf(cx, v3(wi), &col_, pdf);
     rgb[0] = col_.r; rgb[1] = col_.g; rgb[2] = col_.b;

@@ -16,7 +16,12 @@ extern "C" {
 enum {
     ORACLE_SLAB_RECIPROCAL = 1u, /* slab test with a precomputed 1/d, as the kernels do (default: divide, bbox.rs:68-79) */
     ORACLE_BRUTE_FORCE = 2u,     /* ignore TLAS and BLAS: linear scan of instances and triangles */
-    ORACLE_LIBM = 4u             /* libm sin/cos/log/exp/acos/atan2 instead of include/spt_detmath.h */
+    ORACLE_LIBM = 4u,            /* libm sin/cos/log/exp/acos/atan2 instead of include/spt_detmath.h */
+    ORACLE_TIE_MIN_ID = 8u       /* closest hit = min over (t, instance, prim) lexicographically, boxes culled with
+                                    t0 <= t_best: independent of the visit order.  The reference keeps the first
+                                    of two equal-t hits in ITS visit order (triangle.rs:187 `t < inter.t`), which is
+                                    HashMap / BVH-shape dependent; the kernels visit near children first, so the
+                                    GPU parity tests use this rule on both sides. */
 };
 
 typedef struct oracle_stats {

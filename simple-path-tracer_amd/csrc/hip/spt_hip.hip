@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -89,6 +90,51 @@ uint32_t bvh_depth(const spt_bvh_node* nodes, uint32_t n_nodes, uint32_t root, u
         }
     }
     return depth;
+}
+
+// Repack one 32-byte-node tree into 64-byte wide nodes (see trace.h).  Returns the index of the
+// super-root inside `wide` (in wide-node units).
+uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>& wide, const char* what) {
+    auto leaf_ref = [&](const spt_bvh_node& nd) -> uint32_t {
+        uint32_t cnt = nd.b & ~SPT_LEAF_FLAG;
+        if (cnt > 15u) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": BVH leaf with more than 15 items");
+        if (nd.a >= (1u << 27)) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": more than 2^27 items");
+        return kLeaf | (cnt << 27) | nd.a;
+    };
+    auto set_child = [&](uint32_t w, int side, const spt_bvh_node& ch, uint32_t ref) {
+        float4* f = &wide[(size_t)w * 4];
+        float4 lo = make_float4(ch.bmin[0], ch.bmin[1], ch.bmin[2], 0.0f), hi = make_float4(ch.bmax[0], ch.bmax[1], ch.bmax[2], 0.0f);
+        if (side == 0) { f[0].x = lo.x; f[0].y = lo.y; f[0].z = lo.z; f[1].x = hi.x; f[1].y = hi.y; f[1].z = hi.z; std::memcpy(&f[0].w, &ref, 4); }
+        else { f[2] = lo; f[3] = hi; std::memcpy(&f[1].w, &ref, 4); }
+    };
+    auto new_wide = [&]() -> uint32_t {
+        uint32_t w = (uint32_t)(wide.size() / 4);
+        const float inf = std::numeric_limits<float>::infinity();
+        wide.push_back(make_float4(inf, inf, inf, 0.0f));    // empty boxes: never hit
+        wide.push_back(make_float4(-inf, -inf, -inf, 0.0f));
+        wide.push_back(make_float4(inf, inf, inf, 0.0f));
+        wide.push_back(make_float4(-inf, -inf, -inf, 0.0f));
+        return w;
+    };
+    const uint32_t super = new_wide();
+    // iterative: (node index, wide index that receives it, side)
+    struct Item { uint32_t node, parent, side; };
+    std::vector<Item> st;
+    st.push_back(Item{root, super, 0});
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        const spt_bvh_node& nd = nodes[it.node];
+        if (nd.b & SPT_LEAF_FLAG) {
+            set_child(it.parent, (int)it.side, nd, leaf_ref(nd));
+        } else {
+            const uint32_t w = new_wide();
+            set_child(it.parent, (int)it.side, nd, w);
+            st.push_back(Item{nd.b, w, 1});
+            st.push_back(Item{nd.a, w, 0});
+        }
+    }
+    return super;
 }
 
 }  // namespace
@@ -240,8 +286,9 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             // each BLAS must index triangles inside its own mesh range
             blas_depth = std::max(blas_depth, bvh_depth(s.blas_nodes, s.n_blas_nodes, s.meshes[i].root, s.n_tris, "blas"));
         }
-        uint32_t cap = tlas_depth + blas_depth + 4;
-        if (cap * kBlock * 4u > 160u * 1024u) fail(SPT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
+        // near-first traversal pushes at most one (far) child per level
+        uint32_t cap = tlas_depth + blas_depth + 2;
+        if (cap > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (48 levels)");
         sc->tlas.upload(s.tlas_nodes, s.n_tlas_nodes);
         sc->blas.upload(s.blas_nodes, s.n_blas_nodes);
         sc->tri_pos.upload(s.tri_pos, s.n_tris);
@@ -302,17 +349,25 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 if (bytes) std::memcpy(&blob[off], src, bytes);
                 return off;
             };
-            d.o_tlas = append(s.tlas_nodes, (size_t)s.n_tlas_nodes * sizeof(spt_bvh_node));
+            std::vector<float4> wtlas, wblas;
+            d.tlas_root = 0;
+            if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) d.tlas_root = build_wide(s.tlas_nodes, 0, wtlas, "tlas");
+            std::vector<float4> mesh_rec(s.n_meshes, make_float4(0, 0, 0, 0));
+            for (uint32_t i = 0; i < s.n_meshes; ++i) {
+                uint32_t root = build_wide(s.blas_nodes, s.meshes[i].root, wblas, "blas");
+                std::memcpy(&mesh_rec[i].x, &root, 4);
+            }
+            d.o_tlas = append(wtlas.data(), wtlas.size() * 16);
             d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
-            d.o_mesh = append(s.meshes, (size_t)s.n_meshes * sizeof(spt_mesh));
-            d.o_blas = append(s.blas_nodes, (size_t)s.n_blas_nodes * sizeof(spt_bvh_node));
+            d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
+            d.o_blas = append(wblas.data(), wblas.size() * 16);
             d.o_tri = append(s.tri_pos, (size_t)s.n_tris * sizeof(spt_tri_pos));
             d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
             if (blob.size() > 0x7fffffffull / 16) fail(SPT_ERR_UNSUPPORTED, "scene geometry larger than 32 GiB");
             sc->geo.upload(blob.data(), blob.size());
             d.geo = sc->geo.as<float4>();
             d.geo_f4 = (uint32_t)blob.size();
-            const size_t stack_bytes = (size_t)cap * kBlock * sizeof(uint32_t);
+            const size_t stack_bytes = (size_t)kLdsStack * 2 * kBlock * sizeof(uint32_t);   // (ref, t0) per LDS level
             const size_t geo_bytes = blob.size() * 16;
             sc->lds_geo = geo_bytes <= 32u * 1024u && stack_bytes + geo_bytes <= 64u * 1024u;
             sc->lds_bytes = stack_bytes + (sc->lds_geo ? geo_bytes : 0);

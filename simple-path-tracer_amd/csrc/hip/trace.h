@@ -11,11 +11,10 @@
 // Design for the hardware: one ray per lane; nodes are 32 B and triangles 48 B so
 // every fetch is one or a few 16-byte vector loads; the traversal stack lives in
 // LDS, laid out [level][lane] so a wave's pushes and pops hit 64 distinct banks;
-// the per-ray Vec allocation of the reference (bvh.rs:243,267) is gone.  Visit order
-// is the reference's (push left, push right, pop -> right subtree first) so that the
-// closest hit — including which of two equal-t candidates wins — is bit-identical to
-// the CPU oracle.  The slab test multiplies by a per-ray reciprocal instead of the
-// reference's six divisions per node; it only culls, the returned hit is unaffected.
+// the per-ray Vec allocation of the reference (bvh.rs:243,267) is gone.  Nodes are
+// repacked into 64-byte wide nodes and children are visited near-first (see below).
+// The slab test multiplies by a per-ray reciprocal instead of the reference's six
+// divisions per node; it only culls, the returned hit is unaffected.
 #pragma once
 #include "device_math.h"
 
@@ -45,6 +44,7 @@ struct DScene {
     const float4* geo;
     uint32_t geo_f4;           // blob length in float4
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
+    uint32_t tlas_root;        // wide-node index of the TLAS super-root
 };
 
 struct DHit {
@@ -55,10 +55,10 @@ struct DHit {
 
 // per-lane stack in LDS: entry `level` of this lane
 extern __shared__ uint32_t spt_lds_stack[];
-SPT_DEV uint32_t& stack_at(uint32_t level) { return spt_lds_stack[level * blockDim.x + threadIdx.x]; }
+SPT_DEV uint32_t& stack_at(uint32_t word) { return spt_lds_stack[word * blockDim.x + threadIdx.x]; }
 
 // geometry fetch: LDS copy (kLds) or the global blob
-SPT_DEV float4* geo_lds(const DScene& sc) { return reinterpret_cast<float4*>(spt_lds_stack + sc.stack_cap * blockDim.x); }
+SPT_DEV float4* geo_lds(const DScene&) { return reinterpret_cast<float4*>(spt_lds_stack + 2u * 8u * blockDim.x); }  // after the stack (kLdsStack)
 template <bool kLds>
 SPT_DEV float4 geo_ld(const DScene& sc, uint32_t off) {
     if (kLds) return geo_lds(sc)[off];
@@ -146,7 +146,164 @@ SPT_DEV DRay to_object(const DScene& sc, uint32_t inst, const DRay& r, uint32_t*
     return o;
 }
 
-// Closest hit of the scene aggregate.  `base` = first free stack level.
+// ---- wide nodes --------------------------------------------------------------------------
+// The device does not walk the 32-byte nodes of the ABI directly: at scene creation every inner
+// node is repacked into a 64-byte WIDE node that carries the boxes of BOTH children,
+//     f4[0] = (left.bmin,  left ref)   f4[1] = (left.bmax,  right ref)
+//     f4[2] = (right.bmin, -)          f4[3] = (right.bmax, -)
+// ref = inner: wide-node index | leaf: kLeaf | count << 27 | first item.  One fetch (4 x 16 B) gives
+// both slab tests, leaves cost no node fetch, and the nearer child is entered first so the far
+// subtree is usually culled by the hit found in the near one.  Each tree is entered through a
+// super-root whose left child is the real root and whose right child is an empty box.
+// Visit order therefore differs from the reference's (push left, push right, pop), which only
+// matters for exactly equal hit distances: the closest hit is defined as the minimum over
+// (t, instance, prim) and boxes are culled with t0 <= t_best, which is independent of the order
+// (the oracle's ORACLE_TIE_MIN_ID mode applies the same rule).
+constexpr uint32_t kLeaf = 0x80000000u;
+SPT_DEV uint32_t leaf_first(uint32_t ref) { return ref & 0x07ffffffu; }
+SPT_DEV uint32_t leaf_count(uint32_t ref) { return (ref >> 27) & 15u; }
+
+// entry distance of the slab test, or a negative-NaN-free "miss": returns hit flag, t0 through *t0
+SPT_DEV bool slab_t0(float4 lo, float4 hi, f3 o, f3 inv_d, float t_min, float* t0_out) {
+    bool empty = (lo.x > hi.x) | (lo.y > hi.y) | (lo.z > hi.z);
+    float x0 = (lo.x - o.x) * inv_d.x, x1 = (hi.x - o.x) * inv_d.x;
+    float y0 = (lo.y - o.y) * inv_d.y, y1 = (hi.y - o.y) * inv_d.y;
+    float z0 = (lo.z - o.z) * inv_d.z, z1 = (hi.z - o.z) * inv_d.z;
+    float xa = spt_min(x0, x1), xb = spt_max(x0, x1);
+    float ya = spt_min(y0, y1), yb = spt_max(y0, y1);
+    float za = spt_min(z0, z1), zb = spt_max(z0, z1);
+    float t0 = spt_max(xa, spt_max(ya, za));
+    float t1 = spt_min(xb, spt_min(yb, zb));
+    *t0_out = t0;
+    return !empty & (t0 <= t1) & (t1 > t_min);
+}
+
+// Traversal stack: entries are (ref, t0).  The first kLdsStack levels of a lane live in LDS
+// ([word][lane] layout: conflict-free), deeper levels spill to a small private array.  Near-first
+// order keeps the live stack short (it only grows where BOTH children are hit), so the spill is
+// rarely touched, and LDS per workgroup stays at 16 KiB whatever the tree depth — a full-depth LDS
+// stack (58 KiB for the 1 M-triangle scene) would cap the CU at two workgroups.
+constexpr uint32_t kLdsStack = 8;
+constexpr uint32_t kSpillStack = 40;
+struct TStack {
+    uint32_t sp = 0;
+    uint2 spill[kSpillStack];
+    SPT_DEV void push(uint32_t ref, float t0) {
+        if (sp < kLdsStack) {
+            stack_at(2u * sp) = ref;
+            stack_at(2u * sp + 1u) = __float_as_uint(t0);
+        } else {
+            spill[sp - kLdsStack] = make_uint2(ref, __float_as_uint(t0));
+        }
+        ++sp;
+    }
+    SPT_DEV void pop(uint32_t* ref, float* t0) {
+        --sp;
+        if (sp < kLdsStack) {
+            *ref = stack_at(2u * sp);
+            *t0 = __uint_as_float(stack_at(2u * sp + 1u));
+        } else {
+            uint2 e = spill[sp - kLdsStack];
+            *ref = e.x;
+            *t0 = __uint_as_float(e.y);
+        }
+    }
+};
+
+// Near-first walk of one wide-node tree.  `limit` is read on every test, so a closest-hit walk
+// (kClosest: cull with t0 <= limit, the tie rule) tightens as `leaf` lowers it; an any-hit walk culls
+// with t0 < limit.  leaf(first, count) returns true to stop the whole walk (any-hit found).
+template <bool kLds, bool kClosest, class LeafFn>
+SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o, f3 inv_d, float t_min, const float& limit,
+                       TStack& st, LeafFn leaf) {
+    const uint32_t base = st.sp;
+    uint32_t cur = root;
+    while (true) {
+        if (cur & kLeaf) {
+            if (leaf(leaf_first(cur), leaf_count(cur))) { st.sp = base; return true; }
+        } else {
+            const uint32_t n = nodes_off + 4u * cur;
+            float4 a = geo_ld<kLds>(sc, n), b = geo_ld<kLds>(sc, n + 1u), c = geo_ld<kLds>(sc, n + 2u), d = geo_ld<kLds>(sc, n + 3u);
+            float tl, tr;
+            bool hl = slab_t0(a, b, o, inv_d, t_min, &tl);
+            bool hr = slab_t0(c, d, o, inv_d, t_min, &tr);
+            hl = hl && (kClosest ? tl <= limit : tl < limit);
+            hr = hr && (kClosest ? tr <= limit : tr < limit);
+            const uint32_t rl = __float_as_uint(a.w), rr = __float_as_uint(b.w);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                if (st.sp < kLdsStack + kSpillStack) st.push(left_first ? rr : rl, left_first ? tr : tl);
+                cur = left_first ? rl : rr;
+                continue;
+            }
+            if (hl) { cur = rl; continue; }
+            if (hr) { cur = rr; continue; }
+        }
+        // pop the next subtree that can still matter
+        bool found = false;
+        while (st.sp > base) {
+            uint32_t ref;
+            float t0;
+            st.pop(&ref, &t0);
+            if (kClosest ? t0 <= limit : t0 < limit) { cur = ref; found = true; break; }
+        }
+        if (!found) return false;
+    }
+}
+
+SPT_DEV bool key_less(int32_t inst, int32_t prim, const DHit& h) {
+    return (inst < h.inst) || (inst == h.inst && prim < h.prim);
+}
+
+// one instance against the current best hit
+template <bool kLds>
+SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, DHit& h, TStack& st) {
+    uint32_t prim_type, prim_id;
+    DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
+    if (prim_type == SPT_PRIM_SPHERE) {
+        float mn, mx;
+        if (sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx)) {
+            float t = (mn < orr.t_min) ? mx : mn;  // sphere.rs:61
+            if (orr.t_min < t && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)prim_id, h)))) {
+                h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)prim_id; h.v = 0.0f; h.w = 0.0f;
+            }
+        }
+        return;
+    }
+    const uint32_t root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
+    const f3 inv_o = recip3(orr.d);
+    walk_tree<kLds, true>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first; i < first + count; ++i) {
+            float t, v, w;
+            bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
+            if (ok && t > orr.t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)i, h)))) {  // triangle.rs:187
+                h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)i; h.v = v; h.w = w;
+            }
+        }
+        return false;
+    });
+}
+
+template <bool kLds>
+SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, float t_max, TStack& st) {
+    uint32_t prim_type, prim_id;
+    DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
+    if (prim_type == SPT_PRIM_SPHERE) {
+        float mn, mx;
+        return sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx) && mn < t_max && mx > orr.t_min;  // sphere.rs:51-56
+    }
+    const uint32_t root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
+    const f3 inv_o = recip3(orr.d);
+    return walk_tree<kLds, false>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first; i < first + count; ++i) {
+            float t, v, w;
+            if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w) && t > orr.t_min && t < t_max) return true;
+        }
+        return false;
+    });
+}
+
+// Closest hit of the scene aggregate: BvhAccel<Instance> / Group::intersect
 template <bool kLds>
 SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
     DHit h;
@@ -155,68 +312,15 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
     h.prim = -1;
     h.v = 0.0f;
     h.w = 0.0f;
-    const bool group = (sc.aggregate == SPT_AGGREGATE_GROUP);
-    f3 inv_w = recip3(ray.d);
-    uint32_t sp = 0;
-    uint32_t next_inst = 0, end_inst = 0;  // instance range of the current TLAS leaf
-    if (group) {
-        end_inst = sc.n_instances;
+    TStack st;
+    if (sc.aggregate == SPT_AGGREGATE_GROUP) {
+        for (uint32_t i = 0; i < sc.n_instances; ++i) instance_closest<kLds>(sc, i, ray, h, st);
     } else if (sc.n_tlas_nodes > 0) {
-        stack_at(sp++) = 0u;
-    }
-    while (true) {
-        if (next_inst == end_inst) {
-            // pop TLAS nodes until a leaf is entered
-            if (sp == 0) break;
-            uint32_t ni = stack_at(--sp);
-            float4 lo = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni + 1u);
-            if (!slab_test(lo, hi, ray.o, inv_w, ray.t_min, h.t)) continue;
-            uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-            if (b & SPT_LEAF_FLAG) {
-                next_inst = a;
-                end_inst = a + (b & ~SPT_LEAF_FLAG);
-            } else if (sp + 2 <= sc.stack_cap) {
-                stack_at(sp++) = a;
-                stack_at(sp++) = b;
-            }
-            continue;
-        }
-        uint32_t inst = next_inst++;
-        uint32_t prim_type, prim_id;
-        DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
-        if (prim_type == SPT_PRIM_SPHERE) {
-            float mn, mx;
-            if (sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx)) {
-                float t = (mn < orr.t_min) ? mx : mn;  // sphere.rs:61
-                if (orr.t_min < t && t < h.t) {
-                    h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)prim_id; h.v = 0.0f; h.w = 0.0f;
-                }
-            }
-        } else {
-            const uint32_t mesh_root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
-            f3 inv_o = recip3(orr.d);
-            const uint32_t base = sp;
-            stack_at(sp++) = mesh_root;
-            while (sp > base) {
-                uint32_t ni = stack_at(--sp);
-                float4 lo = geo_ld<kLds>(sc, sc.o_blas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_blas + 2u * ni + 1u);
-                if (!slab_test(lo, hi, orr.o, inv_o, orr.t_min, h.t)) continue;
-                uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-                if (b & SPT_LEAF_FLAG) {
-                    uint32_t n = b & ~SPT_LEAF_FLAG;
-                    for (uint32_t i = a; i < a + n; ++i) {
-                        float t, v, w;
-                        bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
-                        if (ok && t > orr.t_min && t < h.t) {  // triangle.rs:187
-                            h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)i; h.v = v; h.w = w;
-                        }
-                    }
-                } else if (sp + 2 <= sc.stack_cap) {
-                    stack_at(sp++) = a;
-                    stack_at(sp++) = b;
-                }
-            }
-        }
+        const f3 inv_w = recip3(ray.d);
+        walk_tree<kLds, true>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
+            for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds>(sc, i, ray, h, st);
+            return false;
+        });
     }
     return h;
 }
@@ -224,59 +328,17 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
 // Any hit in (t_min, t_max): intersect_test of the aggregate
 template <bool kLds>
 SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
-    const bool group = (sc.aggregate == SPT_AGGREGATE_GROUP);
-    f3 inv_w = recip3(ray.d);
-    uint32_t sp = 0;
-    uint32_t next_inst = 0, end_inst = 0;
-    if (group) {
-        end_inst = sc.n_instances;
-    } else if (sc.n_tlas_nodes > 0) {
-        stack_at(sp++) = 0u;
+    TStack st;
+    if (sc.aggregate == SPT_AGGREGATE_GROUP) {
+        for (uint32_t i = 0; i < sc.n_instances; ++i)
+            if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
+        return false;
     }
-    while (true) {
-        if (next_inst == end_inst) {
-            if (sp == 0) break;
-            uint32_t ni = stack_at(--sp);
-            float4 lo = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_tlas + 2u * ni + 1u);
-            if (!slab_test(lo, hi, ray.o, inv_w, ray.t_min, t_max)) continue;
-            uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-            if (b & SPT_LEAF_FLAG) {
-                next_inst = a;
-                end_inst = a + (b & ~SPT_LEAF_FLAG);
-            } else if (sp + 2 <= sc.stack_cap) {
-                stack_at(sp++) = a;
-                stack_at(sp++) = b;
-            }
-            continue;
-        }
-        uint32_t inst = next_inst++;
-        uint32_t prim_type, prim_id;
-        DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
-        if (prim_type == SPT_PRIM_SPHERE) {
-            float mn, mx;
-            if (sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx) && mn < t_max && mx > orr.t_min) return true;  // sphere.rs:51-56
-        } else {
-            const uint32_t mesh_root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
-            f3 inv_o = recip3(orr.d);
-            const uint32_t base = sp;
-            stack_at(sp++) = mesh_root;
-            while (sp > base) {
-                uint32_t ni = stack_at(--sp);
-                float4 lo = geo_ld<kLds>(sc, sc.o_blas + 2u * ni), hi = geo_ld<kLds>(sc, sc.o_blas + 2u * ni + 1u);
-                if (!slab_test(lo, hi, orr.o, inv_o, orr.t_min, t_max)) continue;
-                uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-                if (b & SPT_LEAF_FLAG) {
-                    uint32_t n = b & ~SPT_LEAF_FLAG;
-                    for (uint32_t i = a; i < a + n; ++i) {
-                        float t, v, w;
-                        if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w) && t > orr.t_min && t < t_max) return true;
-                    }
-                } else if (sp + 2 <= sc.stack_cap) {
-                    stack_at(sp++) = a;
-                    stack_at(sp++) = b;
-                }
-            }
-        }
-    }
-    return false;
+    if (sc.n_tlas_nodes == 0) return false;
+    const f3 inv_w = recip3(ray.d);
+    return walk_tree<kLds, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first; i < first + count; ++i)
+            if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
+        return false;
+    });
 }

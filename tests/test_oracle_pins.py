@@ -167,7 +167,7 @@ def test_bvh_equals_brute_force_and_reciprocal_slab(name):
     rays = _util.random_rays(sc, 60_000, seed=3)
     ref = _util.oracle_trace_closest(sc, rays, _util.ORACLE_BRUTE_FORCE)
     assert (ref["instance"] >= 0).mean() > 0.2
-    for flags in (0, _util.ORACLE_SLAB_RECIPROCAL):
+    for flags in (0, _util.ORACLE_SLAB_RECIPROCAL, _util.ORACLE_DEVICE):
         got = _util.oracle_trace_closest(sc, rays, flags)
         # culling cannot change the closest distance, except between coincident surfaces (objects
         # resting on the floor plane): there the slab distance of the flat floor box and the triangle
@@ -193,10 +193,12 @@ def test_render_modes_agree(name, cam):
     r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RANDOM, spp=8, seed=4)
     base, _ = _util.oracle_render(sc, r, 96, 72, camera=cam)
     recip, _ = _util.oracle_render(sc, r, 96, 72, camera=cam, flags=_util.ORACLE_SLAB_RECIPROCAL)
+    device, _ = _util.oracle_render(sc, r, 96, 72, camera=cam, flags=_util.ORACLE_DEVICE)
     brute, _ = _util.oracle_render(sc, r, 96, 72, camera=cam, flags=_util.ORACLE_BRUTE_FORCE)
     libm, _ = _util.oracle_render(sc, r, 96, 72, camera=cam, flags=_util.ORACLE_LIBM)
     scale = max(float(base.mean()), 1e-3)
     assert np.abs(base - recip).mean() / scale < 1e-4
+    assert np.abs(base - device).mean() / scale < 1e-4      # what the GPU parity tests compare against
     assert np.abs(base - brute).mean() / scale < 2e-3
     # libm vs deterministic kernels: 1-ulp direction changes can flip a rare hit, never the statistics
     assert np.abs(base - libm).mean() / scale < 5e-2

@@ -80,7 +80,7 @@ def main():
         rc = spt.PathTracer(r.max_depth, r.sampler, args.check_spp or r.spp, r.division_x, r.division_y, r.filter_radius, r.seed)
         g = rc.render_shard(scene, cfg, shard_index=index, shard_count=count, strip_rows=strip).copy()
         t0 = time.perf_counter()
-        o, ost = _util.oracle_render(scene, rc, w, h, camera=cam, flags=_util.ORACLE_SLAB_RECIPROCAL, shard_index=index,
+        o, ost = _util.oracle_render(scene, rc, w, h, camera=cam, flags=_util.ORACLE_DEVICE, shard_index=index,
                                      shard_count=count, strip_rows=strip)
         dt = time.perf_counter() - t0
         res["check"] = {"rows": int(g.shape[0]), "spp": rc.spp, "mean_L1": float(np.abs(g - o).mean()),
