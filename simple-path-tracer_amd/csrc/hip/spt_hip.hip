@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -93,8 +94,10 @@ uint32_t bvh_depth(const spt_bvh_node* nodes, uint32_t n_nodes, uint32_t root, u
 }
 
 // Repack one 32-byte-node tree into 64-byte wide nodes (see trace.h).  Returns the index of the
-// super-root inside `wide` (in wide-node units).
-uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>& wide, const char* what) {
+// super-root inside `wide` (in wide-node units).  The first `bfs_nodes` wide nodes are numbered
+// breadth-first (they are the ones staged into LDS for large scenes), the subtrees below them
+// depth-first so that deep subtrees stay contiguous in memory.
+uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>& wide, uint32_t bfs_nodes, const char* what) {
     auto leaf_ref = [&](const spt_bvh_node& nd) -> uint32_t {
         uint32_t cnt = nd.b & ~SPT_LEAF_FLAG;
         if (cnt > 15u) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": BVH leaf with more than 15 items");
@@ -116,22 +119,41 @@ uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4
         wide.push_back(make_float4(-inf, -inf, -inf, 0.0f));
         return w;
     };
+    const uint32_t first = (uint32_t)(wide.size() / 4);
     const uint32_t super = new_wide();
-    // iterative: (node index, wide index that receives it, side)
     struct Item { uint32_t node, parent, side; };
-    std::vector<Item> st;
-    st.push_back(Item{root, super, 0});
-    while (!st.empty()) {
-        Item it = st.back();
-        st.pop_back();
+    // breadth-first part
+    std::vector<Item> frontier;
+    frontier.push_back(Item{root, super, 0});
+    size_t head = 0;
+    while (head < frontier.size() && (uint32_t)(wide.size() / 4) - first < bfs_nodes) {
+        Item it = frontier[head++];
         const spt_bvh_node& nd = nodes[it.node];
         if (nd.b & SPT_LEAF_FLAG) {
             set_child(it.parent, (int)it.side, nd, leaf_ref(nd));
         } else {
             const uint32_t w = new_wide();
             set_child(it.parent, (int)it.side, nd, w);
-            st.push_back(Item{nd.b, w, 1});
-            st.push_back(Item{nd.a, w, 0});
+            frontier.push_back(Item{nd.a, w, 0});
+            frontier.push_back(Item{nd.b, w, 1});
+        }
+    }
+    // depth-first below the frontier
+    for (size_t k = head; k < frontier.size(); ++k) {
+        std::vector<Item> st;
+        st.push_back(frontier[k]);
+        while (!st.empty()) {
+            Item it = st.back();
+            st.pop_back();
+            const spt_bvh_node& nd = nodes[it.node];
+            if (nd.b & SPT_LEAF_FLAG) {
+                set_child(it.parent, (int)it.side, nd, leaf_ref(nd));
+            } else {
+                const uint32_t w = new_wide();
+                set_child(it.parent, (int)it.side, nd, w);
+                st.push_back(Item{nd.b, w, 1});
+                st.push_back(Item{nd.a, w, 0});
+            }
         }
     }
     return super;
@@ -349,20 +371,34 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 if (bytes) std::memcpy(&blob[off], src, bytes);
                 return off;
             };
+            // LDS budget of a large scene: what every ray touches first
+            constexpr uint32_t kTopNodes = 256;            // 16 KiB of BLAS top levels
+            constexpr size_t kPrefixBudget = 12u * 1024u;  // TLAS + instances + mesh records + spheres
             std::vector<float4> wtlas, wblas;
             d.tlas_root = 0;
-            if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) d.tlas_root = build_wide(s.tlas_nodes, 0, wtlas, "tlas");
+            if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) d.tlas_root = build_wide(s.tlas_nodes, 0, wtlas, 0xffffffffu, "tlas");
+            // small meshes first (all their nodes land in the staged prefix), the largest mesh last with
+            // its top levels breadth-first
+            std::vector<uint32_t> order(s.n_meshes);
+            for (uint32_t i = 0; i < s.n_meshes; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return s.meshes[x].node_count < s.meshes[y].node_count; });
             std::vector<float4> mesh_rec(s.n_meshes, make_float4(0, 0, 0, 0));
-            for (uint32_t i = 0; i < s.n_meshes; ++i) {
-                uint32_t root = build_wide(s.blas_nodes, s.meshes[i].root, wblas, "blas");
+            uint32_t staged_nodes = 0;
+            for (uint32_t k = 0; k < s.n_meshes; ++k) {
+                const uint32_t i = order[k];
+                const uint32_t before = (uint32_t)(wblas.size() / 4);
+                const uint32_t room = before < kTopNodes ? kTopNodes - before : 0u;
+                uint32_t root = build_wide(s.blas_nodes, s.meshes[i].root, wblas, room, "blas");
                 std::memcpy(&mesh_rec[i].x, &root, 4);
+                staged_nodes = std::min<uint32_t>((uint32_t)(wblas.size() / 4), kTopNodes);
             }
             d.o_tlas = append(wtlas.data(), wtlas.size() * 16);
             d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
             d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
+            d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
+            const size_t prefix_bytes = blob.size() * 16;
             d.o_blas = append(wblas.data(), wblas.size() * 16);
             d.o_tri = append(s.tri_pos, (size_t)s.n_tris * sizeof(spt_tri_pos));
-            d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
             if (blob.size() > 0x7fffffffull / 16) fail(SPT_ERR_UNSUPPORTED, "scene geometry larger than 32 GiB");
             sc->geo.upload(blob.data(), blob.size());
             d.geo = sc->geo.as<float4>();
@@ -370,7 +406,10 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             const size_t stack_bytes = (size_t)kLdsStack * 2 * kBlock * sizeof(uint32_t);   // (ref, t0) per LDS level
             const size_t geo_bytes = blob.size() * 16;
             sc->lds_geo = geo_bytes <= 32u * 1024u && stack_bytes + geo_bytes <= 64u * 1024u;
-            sc->lds_bytes = stack_bytes + (sc->lds_geo ? geo_bytes : 0);
+            if (sc->lds_geo) d.lds_f4 = d.geo_f4;
+            else d.lds_f4 = 0;   // large scene: global fetches only (see trace.h)
+            (void)prefix_bytes; (void)staged_nodes; (void)kPrefixBudget;
+            sc->lds_bytes = stack_bytes + (size_t)d.lds_f4 * 16;
         }
         bool simple = s.env.width == 0 && s.n_lights > 0;
         for (uint32_t i = 0; i < s.n_materials; ++i) simple = simple && s.materials[i].bxdf == SPT_BXDF_LAMBERT;
@@ -479,7 +518,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         sc->hit_f4.ensure(cap * 16);
         sc->hit_inst.ensure(cap * 4);
         for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
-        const size_t counts_words = (size_t)(p.max_depth + 1) * 3 * kShards * 32;
+        const size_t counts_words = (size_t)(p.max_depth + 1) * Q_KINDS * kShards * 32;
         const size_t counts_bytes = counts_words * sizeof(uint32_t);
         sc->counts.ensure(counts_bytes);
         sc->rad.ensure((size_t)rad64 * 3 * sizeof(float));
@@ -526,6 +565,14 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
         const size_t lds = sc->lds_bytes;
         const bool L = sc->lds_geo;
+        // refilling persistent waves for large scenes: on for shadow rays (any-hit walks end at very
+        // different times: 10.9 -> 8.8 ms on the 1 M-triangle scene), off for extension rays (28 vs 20 ms)
+        const bool dyn_shadow = !L && std::getenv("SPT_NO_DYN_SHADOW") == nullptr;
+        const bool dyn_extend = !L && std::getenv("SPT_DYN_EXTEND") != nullptr;
+        auto env_u32 = [](const char* name, uint32_t dflt) { const char* v = std::getenv(name); return v ? (uint32_t)std::atoi(v) : dflt; };
+        const uint32_t kDynBlocks = env_u32("SPT_DYN_BLOCKS", 2048);   // persistent blocks that pull work
+        rc.dyn_refill_below = env_u32("SPT_DYN_REFILL", kRefillBelow);
+        rc.dyn_steps = env_u32("SPT_DYN_STEPS", kStepsPerCheck);
         struct Span { int cls; size_t e0; };
         std::vector<Span> spans;
         size_t ev_used = 0;
@@ -570,11 +617,13 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 end();
                 begin(SPT_K_SHADOW);
                 if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                 else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                 end();
                 if (b + 1 < p.max_depth) {
                     begin(SPT_K_EXTEND);
                     if (L) hipLaunchKernelGGL(k_extend<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                    else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                     else hipLaunchKernelGGL(k_extend<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                     end();
                 }
@@ -589,7 +638,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 seg_closest += (uint64_t)n_pix * rc.pass_samples;
                 auto qsum = [&](uint32_t b, uint32_t q) {
                     uint64_t t = 0;
-                    for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * 3 + q) * kShards + s) * 32];
+                    for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * Q_KINDS + q) * kShards + s) * 32];
                     return t;
                 };
                 primary_hits += qsum(0, Q_HIT);

@@ -38,11 +38,15 @@ struct DScene {
     uint32_t env_w, env_h;
     float env_scale[3];
     uint32_t stack_cap;        // LDS stack entries per lane the scene needs
-    // Traversal geometry as ONE float4 blob [tlas | instances | meshes | blas | tri_pos | spheres]
-    // (offsets in float4 units).  Small scenes are staged into LDS once per workgroup
-    // (k_*<true>) and every node / triangle / instance fetch becomes a ds_read_b128.
+    // Traversal geometry as ONE float4 blob [tlas | instances | meshes | spheres | blas | tri_pos]
+    // (offsets in float4 units).  The first lds_f4 float4 are staged into LDS once per workgroup:
+    //   small scenes (k_*<true>): the whole blob, every fetch is a ds_read_b128;
+    //   large scenes (k_*<false>): nothing (lds_f4 = 0).  Staging TLAS + instances + the top 256 BLAS
+    //   nodes was MEASURED slower on the 1 M-triangle scene (613 -> 527 Msamples/s): those records
+    //   are L1/L2-hot anyway and the per-fetch "staged or global?" branch costs more than it saves.
     const float4* geo;
     uint32_t geo_f4;           // blob length in float4
+    uint32_t lds_f4;           // staged prefix length in float4 (== geo_f4 for k_*<true>)
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
     uint32_t tlas_root;        // wide-node index of the TLAS super-root
 };
@@ -64,14 +68,18 @@ SPT_DEV float4 geo_ld(const DScene& sc, uint32_t off) {
     if (kLds) return geo_lds(sc)[off];
     return sc.geo[off];
 }
+// triangles are never in the staged prefix of a large scene
+template <bool kLds>
+SPT_DEV float4 geo_ld_tri(const DScene& sc, uint32_t off) {
+    if (kLds) return geo_lds(sc)[off];
+    return sc.geo[off];
+}
 // once per workgroup, before any traversal
 template <bool kLds>
 SPT_DEV void stage_geometry(const DScene& sc) {
-    if (kLds) {
-        float4* dst = geo_lds(sc);
-        for (uint32_t i = threadIdx.x; i < sc.geo_f4; i += blockDim.x) dst[i] = sc.geo[i];
-        __syncthreads();
-    }
+    float4* dst = geo_lds(sc);
+    for (uint32_t i = threadIdx.x; i < sc.lds_f4; i += blockDim.x) dst[i] = sc.geo[i];
+    __syncthreads();
 }
 
 SPT_DEV f3 recip3(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
@@ -116,7 +124,7 @@ SPT_DEV bool tri_test(const float4* tri_pos, uint32_t tri, const DRay& r, float*
 template <bool kLds>
 SPT_DEV bool tri_test_geo(const DScene& sc, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
     const uint32_t o = sc.o_tri + 3u * tri;
-    return tri_test3(geo_ld<kLds>(sc, o), geo_ld<kLds>(sc, o + 1), geo_ld<kLds>(sc, o + 2), r, t, v_out, w_out);
+    return tri_test3(geo_ld_tri<kLds>(sc, o), geo_ld_tri<kLds>(sc, o + 1), geo_ld_tri<kLds>(sc, o + 2), r, t, v_out, w_out);
 }
 
 // Sphere::intersect_ray (sphere.rs:25-39)
@@ -187,7 +195,8 @@ constexpr uint32_t kLdsStack = 8;
 constexpr uint32_t kSpillStack = 40;
 struct TStack {
     uint32_t sp = 0;
-    uint2 spill[kSpillStack];
+    uint2* spill;   // kSpillStack private entries owned by the caller (kept out of this struct so that
+                    // the dynamically indexed array does not drag the other fields into scratch)
     SPT_DEV void push(uint32_t ref, float t0) {
         if (sp < kLdsStack) {
             stack_at(2u * sp) = ref;
@@ -312,7 +321,9 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
     h.prim = -1;
     h.v = 0.0f;
     h.w = 0.0f;
+    uint2 spill_mem[kSpillStack];
     TStack st;
+    st.spill = spill_mem;
     if (sc.aggregate == SPT_AGGREGATE_GROUP) {
         for (uint32_t i = 0; i < sc.n_instances; ++i) instance_closest<kLds>(sc, i, ray, h, st);
     } else if (sc.n_tlas_nodes > 0) {
@@ -328,7 +339,9 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
 // Any hit in (t_min, t_max): intersect_test of the aggregate
 template <bool kLds>
 SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
+    uint2 spill_mem[kSpillStack];
     TStack st;
+    st.spill = spill_mem;
     if (sc.aggregate == SPT_AGGREGATE_GROUP) {
         for (uint32_t i = 0; i < sc.n_instances; ++i)
             if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
@@ -342,3 +355,141 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
         return false;
     });
 }
+
+// ---- resumable traversal -----------------------------------------------------------------------
+// The same walk as trace_closest / trace_any (identical visit order and arithmetic per ray), written
+// as a state machine that advances ONE step per call.  It exists for incoherent rays on large scenes:
+// with the nested loops above a wave runs until its slowest lane is done (measured on the 1 M-triangle
+// scene: 16 % of the lanes active in the shadow kernel, 30 % in extend), whereas a stepping walker
+// lets a persistent wave hand a finished lane the next ray of the queue while the others continue.
+template <bool kLds, bool kClosest>
+struct Walker {
+    f3 o, d, inv_w;            // world ray
+    float t_min;
+    f3 oo, od, inv_o;          // ray in the space of the current instance
+    uint32_t cur;              // ref being processed (phase 1: TLAS, phase 2: BLAS)
+    uint32_t phase;            // 0: next instance of the leaf / TLAS pop, 1: TLAS ref, 2: BLAS ref
+    uint32_t inst, inst_next, inst_end, blas_base;
+    TStack st;
+    DHit h;                    // kClosest: best hit; else h.t = t_max and h.inst >= 0 means "occluded"
+    bool done;
+
+    SPT_DEV void start(const DScene& sc, const DRay& r, float t_max, uint2* spill_mem) {
+        st.spill = spill_mem;
+        o = r.o; d = r.d; t_min = r.t_min;
+        inv_w = recip3(r.d);
+        h.t = t_max; h.inst = -1; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
+        st.sp = 0;
+        done = false;
+        inst_next = 0; inst_end = 0; blas_base = 0; inst = 0; cur = 0;
+        if (sc.aggregate == SPT_AGGREGATE_GROUP) {
+            inst_end = sc.n_instances;
+            phase = 0;
+        } else if (sc.n_tlas_nodes > 0) {
+            cur = sc.tlas_root;
+            phase = 1;
+        } else {
+            phase = 0;
+        }
+    }
+    SPT_DEV bool passes(float t0) const { return kClosest ? t0 <= h.t : t0 < h.t; }
+
+    // descend into the children of wide node `node`; returns false if neither child is hit
+    SPT_DEV bool enter(const DScene& sc, uint32_t nodes_off, f3 ro, f3 rinv) {
+        const uint32_t n = nodes_off + 4u * cur;
+        float4 a = geo_ld<kLds>(sc, n), b = geo_ld<kLds>(sc, n + 1u), c = geo_ld<kLds>(sc, n + 2u), e = geo_ld<kLds>(sc, n + 3u);
+        float tl, tr;
+        bool hl = slab_t0(a, b, ro, rinv, t_min, &tl);
+        bool hr = slab_t0(c, e, ro, rinv, t_min, &tr);
+        hl = hl && passes(tl);
+        hr = hr && passes(tr);
+        const uint32_t rl = __float_as_uint(a.w), rr = __float_as_uint(b.w);
+        if (hl && hr) {
+            const bool left_first = tl <= tr;
+            if (st.sp < kLdsStack + kSpillStack) st.push(left_first ? rr : rl, left_first ? tr : tl);
+            cur = left_first ? rl : rr;
+            return true;
+        }
+        if (hl) { cur = rl; return true; }
+        if (hr) { cur = rr; return true; }
+        return false;
+    }
+    SPT_DEV bool pop_to(uint32_t base) {
+        while (st.sp > base) {
+            uint32_t ref;
+            float t0;
+            st.pop(&ref, &t0);
+            if (passes(t0)) { cur = ref; return true; }
+        }
+        return false;
+    }
+
+    SPT_DEV void step(const DScene& sc) {
+        if (phase == 2u) {  // inside the BLAS of `inst`
+            if (cur & kLeaf) {
+                const uint32_t first = leaf_first(cur), count = leaf_count(cur);
+                for (uint32_t i = first; i < first + count; ++i) {
+                    float t, v, w;
+                    DRay orr;
+                    orr.o = oo; orr.d = od; orr.t_min = t_min;
+                    bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
+                    if (kClosest) {
+                        if (ok && t > t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)i, h)))) {
+                            h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)i; h.v = v; h.w = w;
+                        }
+                    } else if (ok && t > t_min && t < h.t) {
+                        h.inst = (int32_t)inst;
+                        done = true;
+                        return;
+                    }
+                }
+            } else if (enter(sc, sc.o_blas, oo, inv_o)) {
+                return;
+            }
+            if (!pop_to(blas_base)) phase = 0u;
+            return;
+        }
+        if (phase == 1u) {  // a TLAS ref
+            if (cur & kLeaf) {
+                inst_next = leaf_first(cur);
+                inst_end = inst_next + leaf_count(cur);
+                phase = 0u;
+                return;
+            }
+            if (!enter(sc, sc.o_tlas, o, inv_w)) phase = 0u;
+            return;
+        }
+        // phase 0: next instance of the current leaf, else pop the TLAS stack
+        if (inst_next < inst_end) {
+            inst = inst_next++;
+            uint32_t prim_type, prim_id;
+            DRay wr;
+            wr.o = o; wr.d = d; wr.t_min = t_min;
+            DRay orr = to_object<kLds>(sc, inst, wr, &prim_type, &prim_id);
+            if (prim_type == SPT_PRIM_SPHERE) {
+                float mn, mx;
+                bool roots = sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx);
+                if (kClosest) {
+                    if (roots) {
+                        float t = (mn < orr.t_min) ? mx : mn;
+                        if (orr.t_min < t && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)prim_id, h)))) {
+                            h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)prim_id; h.v = 0.0f; h.w = 0.0f;
+                        }
+                    }
+                } else if (roots && mn < h.t && mx > orr.t_min) {
+                    h.inst = (int32_t)inst;
+                    done = true;
+                }
+                return;
+            }
+            oo = orr.o; od = orr.d;
+            inv_o = recip3(orr.d);
+            cur = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
+            blas_base = st.sp;
+            phase = 2u;
+            return;
+        }
+        if (pop_to(0u)) { phase = 1u; return; }
+        done = true;
+    }
+};
