@@ -196,9 +196,16 @@ def main():
         dom_name = max(kern, key=lambda n: kern[n]["ms_per_step"]) if kern else "primary"
         dom = kern.get(dom_name, {"GBps": 0.0, "frac": 0.0, "avg_launch_ms": None, "alg_MB_per_launch": None})
         pipeline_bytes = sum(alg.values())
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected in a
+        # separate rocprofv3 --pmc run of this same command and committed under profiles/ (tools/pmc_traffic.py)
+        traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r01_traffic_bench.json")
+        if os.path.exists(traffic_src) and world == 1 and args.samples_per_pass == 0 and args.spp == 256:
+            tk = json.load(open(traffic_src))["kernels"].get("k_" + dom_name)
+            if tk and tk["launches"] == dom.get("launches_per_step"):
+                traffic = round(tk["hbm_bytes_per_launch"] / 1e6, 3)
         roofline = {
             "bound": "hbm", "kernel": "k_" + dom_name, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["frac"], "traffic": None,
+            "frac": dom["frac"], "traffic": traffic, "traffic_unit": "MB per launch (PMC, profiles/r01_traffic_bench.json)",
             "avg_launch_ms": dom["avg_launch_ms"], "alg_MB_per_launch": dom["alg_MB_per_launch"],
             "kernels": kern,
             "pipeline": {"alg_bytes_per_sample": round(pipeline_bytes / max(smp, 1), 2),

@@ -492,7 +492,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         // samples per pass: keep the queues around a few million entries
         uint32_t spp_pass = p.samples_per_pass;
         if (spp_pass == 0) {
-            const uint64_t target = 64ull << 20;
+            const uint64_t target = 128ull << 20;
             spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
         }
         spp_pass = std::min(spp_pass, p.spp);

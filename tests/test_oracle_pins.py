@@ -216,3 +216,24 @@ def test_thread_count_and_sharding_do_not_change_the_image():
         rows = spt.shard_rows(48, k, 3, 4)
         out[rows], _ = _util.oracle_render(sc, r, 64, 48, camera="main", shard_index=k, shard_count=3, strip_rows=4)
     assert np.array_equal(a.view(np.uint32), out.view(np.uint32))
+
+
+def test_tie_rule_is_order_independent(tmp_path):
+    """Two instances of the same quad at the same place: every hit is an exact tie.  The reference rule
+    keeps the first instance in visit order; ORACLE_TIE_MIN_ID keeps the smallest (instance, prim),
+    whatever the order (BVH, brute force)."""
+    quad = "v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n"
+    sc = _write_scene(tmp_path, [{"type": "trimesh", "name": "q", "obj_file": "q.obj"}],
+                      [{"name": "a", "primitive": "q", "material": "m"}, {"name": "b", "primitive": "q", "material": "m"}],
+                      {"q.obj": quad}, {"aggregate": "bvh"})
+    rng = np.random.default_rng(0)
+    o = np.c_[rng.uniform(-0.9, 0.9, (500, 2)), np.full(500, 3.0)]
+    rays = _rays(o, np.tile([0.0, 0.0, -1.0], (500, 1)))
+    ref = _util.oracle_trace_closest(sc, rays, 0)
+    tie = _util.oracle_trace_closest(sc, rays, _util.ORACLE_TIE_MIN_ID)
+    brute = _util.oracle_trace_closest(sc, rays, _util.ORACLE_TIE_MIN_ID | _util.ORACLE_BRUTE_FORCE)
+    assert (ref["t"] == 3.0).all() and (tie["t"] == 3.0).all()
+    assert (tie["instance"] == 0).all() and np.array_equal(tie["prim"], brute["prim"]) and (brute["instance"] == 0).all()
+    # on the shared diagonal both triangles of the quad tie as well: the lower prim index wins
+    diag = _rays([[0.3, 0.3, 3.0]], [[0.0, 0.0, -1.0]])
+    assert _util.oracle_trace_closest(sc, diag, _util.ORACLE_TIE_MIN_ID)["prim"][0] == 0
