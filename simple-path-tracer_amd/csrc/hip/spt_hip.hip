@@ -376,20 +376,27 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             constexpr size_t kPrefixBudget = 12u * 1024u;  // TLAS + instances + mesh records + spheres
             std::vector<float4> wtlas, wblas;
             d.tlas_root = 0;
-            if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) d.tlas_root = build_wide(s.tlas_nodes, 0, wtlas, 0xffffffffu, "tlas");
+            for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = 0.0f; d.tlas_hi[k] = 0.0f; }
+            if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) {
+                const uint32_t sup = build_wide(s.tlas_nodes, 0, wtlas, 0xffffffffu, "tlas");
+                std::memcpy(&d.tlas_root, &wtlas[(size_t)sup * 4].w, 4);      // left child of the super-root = real root
+                for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = s.tlas_nodes[0].bmin[k]; d.tlas_hi[k] = s.tlas_nodes[0].bmax[k]; }
+            }
             // small meshes first (all their nodes land in the staged prefix), the largest mesh last with
             // its top levels breadth-first
             std::vector<uint32_t> order(s.n_meshes);
             for (uint32_t i = 0; i < s.n_meshes; ++i) order[i] = i;
             std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return s.meshes[x].node_count < s.meshes[y].node_count; });
-            std::vector<float4> mesh_rec(s.n_meshes, make_float4(0, 0, 0, 0));
+            std::vector<float4> mesh_rec((size_t)s.n_meshes * 2, make_float4(0, 0, 0, 0));   // (root.lo, root ref) (root.hi, -)
             uint32_t staged_nodes = 0;
             for (uint32_t k = 0; k < s.n_meshes; ++k) {
                 const uint32_t i = order[k];
                 const uint32_t before = (uint32_t)(wblas.size() / 4);
                 const uint32_t room = before < kTopNodes ? kTopNodes - before : 0u;
-                uint32_t root = build_wide(s.blas_nodes, s.meshes[i].root, wblas, room, "blas");
-                std::memcpy(&mesh_rec[i].x, &root, 4);
+                const uint32_t sup = build_wide(s.blas_nodes, s.meshes[i].root, wblas, room, "blas");
+                const spt_bvh_node& rn = s.blas_nodes[s.meshes[i].root];
+                mesh_rec[2 * i] = make_float4(rn.bmin[0], rn.bmin[1], rn.bmin[2], wblas[(size_t)sup * 4].w);
+                mesh_rec[2 * i + 1] = make_float4(rn.bmax[0], rn.bmax[1], rn.bmax[2], 0.0f);
                 staged_nodes = std::min<uint32_t>((uint32_t)(wblas.size() / 4), kTopNodes);
             }
             d.o_tlas = append(wtlas.data(), wtlas.size() * 16);

@@ -48,7 +48,8 @@ struct DScene {
     uint32_t geo_f4;           // blob length in float4
     uint32_t lds_f4;           // staged prefix length in float4 (== geo_f4 for k_*<true>)
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
-    uint32_t tlas_root;        // wide-node index of the TLAS super-root
+    uint32_t tlas_root;        // ref of the TLAS root (wide-node index or leaf ref)
+    float tlas_lo[3], tlas_hi[3];  // its box
 };
 
 struct DHit {
@@ -161,8 +162,9 @@ SPT_DEV DRay to_object(const DScene& sc, uint32_t inst, const DRay& r, uint32_t*
 //     f4[2] = (right.bmin, -)          f4[3] = (right.bmax, -)
 // ref = inner: wide-node index | leaf: kLeaf | count << 27 | first item.  One fetch (4 x 16 B) gives
 // both slab tests, leaves cost no node fetch, and the nearer child is entered first so the far
-// subtree is usually culled by the hit found in the near one.  Each tree is entered through a
-// super-root whose left child is the real root and whose right child is an empty box.
+// subtree is usually culled by the hit found in the near one.  The box and ref of each tree's ROOT
+// live in the mesh record (BLAS, 2 x float4 per mesh) / in DScene (TLAS), so entering a tree costs
+// one slab test and no node fetch.
 // Visit order therefore differs from the reference's (push left, push right, pop), which only
 // matters for exactly equal hit distances: the closest hit is defined as the minimum over
 // (t, instance, prim) and boxes are culled with t0 <= t_best, which is independent of the order
@@ -260,6 +262,14 @@ SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o
     }
 }
 
+// root box test of a tree: true if the walk has to start (closest: t0 <= limit, any: t0 < limit)
+template <bool kClosest>
+SPT_DEV bool root_hit(float4 lo, float4 hi, f3 o, f3 inv_d, float t_min, float limit) {
+    float t0;
+    bool hit = slab_t0(lo, hi, o, inv_d, t_min, &t0);
+    return hit && (kClosest ? t0 <= limit : t0 < limit);
+}
+
 SPT_DEV bool key_less(int32_t inst, int32_t prim, const DHit& h) {
     return (inst < h.inst) || (inst == h.inst && prim < h.prim);
 }
@@ -279,8 +289,10 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
         }
         return;
     }
-    const uint32_t root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
+    const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
+    const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(orr.d);
+    if (!root_hit<true>(rlo, rhi, orr.o, inv_o, orr.t_min, h.t)) return;
     walk_tree<kLds, true>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
@@ -301,8 +313,10 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
         float mn, mx;
         return sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx) && mn < t_max && mx > orr.t_min;  // sphere.rs:51-56
     }
-    const uint32_t root = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
+    const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
+    const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(orr.d);
+    if (!root_hit<false>(rlo, rhi, orr.o, inv_o, orr.t_min, t_max)) return false;
     return walk_tree<kLds, false>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
@@ -328,6 +342,8 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
         for (uint32_t i = 0; i < sc.n_instances; ++i) instance_closest<kLds>(sc, i, ray, h, st);
     } else if (sc.n_tlas_nodes > 0) {
         const f3 inv_w = recip3(ray.d);
+        const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
+        if (root_hit<true>(tlo, thi, ray.o, inv_w, ray.t_min, h.t))
         walk_tree<kLds, true>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
             for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds>(sc, i, ray, h, st);
             return false;
@@ -349,6 +365,8 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
     }
     if (sc.n_tlas_nodes == 0) return false;
     const f3 inv_w = recip3(ray.d);
+    const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
+    if (!root_hit<false>(tlo, thi, ray.o, inv_w, ray.t_min, t_max)) return false;
     return walk_tree<kLds, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i)
             if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
@@ -386,10 +404,13 @@ struct Walker {
             inst_end = sc.n_instances;
             phase = 0;
         } else if (sc.n_tlas_nodes > 0) {
+            const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
             cur = sc.tlas_root;
             phase = 1;
+            if (!root_hit<kClosest>(tlo, thi, o, inv_w, t_min, h.t)) { phase = 0; done = true; }
         } else {
             phase = 0;
+            done = true;
         }
     }
     SPT_DEV bool passes(float t0) const { return kClosest ? t0 <= h.t : t0 < h.t; }
@@ -484,7 +505,9 @@ struct Walker {
             }
             oo = orr.o; od = orr.d;
             inv_o = recip3(orr.d);
-            cur = __float_as_uint(geo_ld<kLds>(sc, sc.o_mesh + prim_id).x);
+            const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
+            if (!root_hit<kClosest>(rlo, rhi, oo, inv_o, t_min, h.t)) return;   // stays in phase 0: next instance
+            cur = __float_as_uint(rlo.w);
             blas_base = st.sp;
             phase = 2u;
             return;
