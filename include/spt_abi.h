@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 1
+#define SPT_ABI_VERSION 2
 
 typedef int32_t spt_status;
 enum {
@@ -118,16 +118,25 @@ enum {
     SPT_BXDF_SPECULAR_CONDUCTOR = 2,   /* src/bxdf/specular_conductor.rs    */
     SPT_BXDF_MICROFACET_DIELECTRIC = 3,/* src/bxdf/microfacet_dielectric.rs */
     SPT_BXDF_SPECULAR_DIELECTRIC = 4,  /* src/bxdf/specular_dielectric.rs   */
-    SPT_BXDF_PSEUDO = 5                /* src/bxdf/pseudo.rs                */
+    SPT_BXDF_PSEUDO = 5,               /* src/bxdf/pseudo.rs                */
+    SPT_BXDF_MICROFACET_PLASTIC = 6,   /* src/bxdf/microfacet_plastic.rs    */
+    SPT_BXDF_SPECULAR_PLASTIC = 7      /* src/bxdf/specular_plastic.rs      */
 };
+/* plastic lobes = Fresnel-weighted specular coat over a substrate (materials plastic, pbr_metallic,
+ * pbr_specular; src/material/{plastic,pbr_metallic,pbr_specular}.rs) */
+enum { SPT_FRESNEL_DIELECTRIC = 0, SPT_FRESNEL_SCHLICK = 1 };   /* src/bxdf/fresnel.rs:19-59 */
+enum { SPT_SUBSTRATE_LAMBERT = 0, SPT_SUBSTRATE_DIFFUSE = 1 };  /* src/bxdf/substrate.rs:22-45,120-180 */
 typedef struct spt_material {
     uint32_t bxdf;
-    float c0[3];     /* lambert: reflectance; conductor: ior (eta)         */
-    float c1[3];     /* conductor: ior_k                                   */
-    float ax, ay;    /* GGX roughness_x / roughness_y (already squared)    */
-    float ior;       /* dielectric: int_ior / ext_ior                      */
-    float pad[2];
-} spt_material;      /* 12 words */
+    float c0[3];     /* lambert: reflectance; conductor: ior (eta); plastic: substrate reflectance */
+    float c1[3];     /* conductor: ior_k; plastic with Schlick Fresnel: r0                         */
+    float ax, ay;    /* GGX roughness_x / roughness_y (as the material hands them to GgxMicrofacet) */
+    float ior;       /* dielectric / plastic: int_ior / ext_ior                                     */
+    float c2[3];     /* Diffuse substrate: bxdf_wo_fresnel (Diffuse::new, substrate.rs:127-137)     */
+    uint32_t fresnel;    /* SPT_FRESNEL_*   (plastic lobes) */
+    uint32_t substrate;  /* SPT_SUBSTRATE_* (plastic lobes) */
+    float pad;
+} spt_material;      /* 16 words = 64 B */
 
 enum { SPT_SURF_DOUBLE_SIDED = 1u };
 typedef struct spt_surface {  /* src/core/surface.rs:14-22 (no maps: scalar-texture scope) */

@@ -585,6 +585,28 @@ inline Color mat_fresnel(const spt_material& mt, Vec3 i, Vec3 n) {  // src/bxdf/
         return fresnel_conductor_n(col(mt.c0), col(mt.c1), i, n);
     return gray(fresnel_n(mt.ior, i, n));
 }
+// SchlickFresnel::fresnel (fresnel.rs:49-52) = schlick_fresnel_with_r0 (util.rs:119-121), cos = i.n unclamped
+inline float pow5(float x) { return x * x * x * x * x; }
+inline Color plastic_fresnel(const spt_material& mt, Vec3 i, Vec3 n) {
+    if (mt.fresnel == SPT_FRESNEL_SCHLICK) {
+        Color r0 = col(mt.c1);
+        return r0 + (gray(1.0f) - r0) * pow5(1.0f - dot(i, n));
+    }
+    return gray(fresnel_n(mt.ior, i, n));
+}
+// SubstrateT for Lambert (substrate.rs:29-45) and Diffuse (substrate.rs:139-180)
+inline Color substrate_reflectance(const spt_material& mt) { return col(mt.c0); }
+inline float substrate_pdf(const spt_material&, Vec3 wo, Vec3 wi) {
+    return (wo.z * wi.z >= 0.0f) ? spt_abs(wi.z) * SPT_FRAC_1_PI : 1.0f;
+}
+inline Color substrate_eval(const spt_material& mt, Vec3 wo, Vec3 wi) {
+    if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
+    if (mt.substrate == SPT_SUBSTRATE_DIFFUSE) {
+        float fi = fresnel_n(mt.ior, wi, v3(0, 0, 1));
+        return (1.0f - fi) * col(mt.c2);
+    }
+    return col(mt.c0) * SPT_FRAC_1_PI;
+}
 inline float ndf_visible(const spt_material& mt, Vec3 wo, Vec3 wi, Vec3 h) {  // src/bxdf/microfacet.rs:47-53
     float ndf = ggx_ndf_aniso(h, mt.ax, mt.ay);
     float vis = smith_separable_visible_aniso(wo, wi, mt.ax, mt.ay);
@@ -677,6 +699,75 @@ BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng)
         }
         return s;
     }
+    case SPT_BXDF_MICROFACET_PLASTIC:
+    case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:26-79, specular_plastic.rs:19-63
+        const bool rough = mt.bxdf == SPT_BXDF_MICROFACET_PLASTIC;
+        Color fresnel_macro = plastic_fresnel(mt, wo, v3(0, 0, 1));
+        float specular_weight = luminance(fresnel_macro);
+        float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * substrate_reflectance(mt));
+        float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
+        s.dir = REFLECT;
+        if (rng.uniform_1d() < reflect_pdf) {
+            Vec3 wi;
+            Color specular_bxdf;
+            float specular_pdf;
+            if (rough) {
+                float r0, r1, half_pdf;
+                rng.uniform_2d(&r0, &r1);
+                Vec3 half = ggx_smith_vndf_sample(m, wo, mt.ax, mt.ay, r0, r1, &half_pdf);
+                Color fr = plastic_fresnel(mt, wo, half);
+                wi = reflect_n(wo, half);
+                specular_bxdf = fr * ndf_visible(mt, wo, wi, half);
+                specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+            } else {
+                wi = reflect(wo);
+                specular_bxdf = fresnel_macro / spt_abs(wi.z);
+                specular_pdf = reflect_pdf;
+            }
+            Color substrate_bxdf = (gray(1.0f) - fresnel_macro) * substrate_eval(mt, wo, wi);
+            float sub_pdf = (1.0f - reflect_pdf) * substrate_pdf(mt, wo, wi);
+            s.wi = wi;
+            s.bxdf = specular_bxdf + substrate_bxdf;
+            s.pdf = specular_pdf + sub_pdf;
+        } else {
+            // substrate.sample: cosine hemisphere (Lambert::sample / Diffuse::sample)
+            float rx, ry;
+            rng.uniform_2d(&rx, &ry);
+            float phi = rx * 2.0f * SPT_PI;
+            float sp, cp;
+            m.sincos(phi, &sp, &cp);
+            float sin_theta = spt_sqrt(ry);
+            float cos_theta = spt_sqrt(1.0f - ry);
+            Vec3 wi = v3(sin_theta * cp, sin_theta * sp, cos_theta);
+            if (wo.z < 0.0f) wi.z = -wi.z;
+            Color samp_bxdf;
+            if (mt.substrate == SPT_SUBSTRATE_DIFFUSE) {
+                float fi = fresnel_n(mt.ior, wi, v3(0, 0, 1));
+                samp_bxdf = (1.0f - fi) * col(mt.c2);
+            } else {
+                samp_bxdf = col(mt.c0) * SPT_FRAC_1_PI;
+            }
+            float samp_pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
+            float sub_pdf = (1.0f - reflect_pdf) * samp_pdf;
+            Color substrate_bxdf = (gray(1.0f) - fresnel_macro) * samp_bxdf;
+            Color specular_bxdf;
+            float specular_pdf;
+            if (rough) {
+                Vec3 half = half_from_reflect(wo, wi);
+                float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+                specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+                Color fr = plastic_fresnel(mt, wo, half);
+                specular_bxdf = fr * ndf_visible(mt, wo, wi, half);
+            } else {
+                specular_pdf = reflect_pdf;
+                specular_bxdf = fresnel_macro / spt_abs(wi.z);
+            }
+            s.wi = wi;
+            s.bxdf = substrate_bxdf + specular_bxdf;
+            s.pdf = sub_pdf + specular_pdf;
+        }
+        return s;
+    }
     default: {  // SPT_BXDF_PSEUDO, src/bxdf/pseudo.rs:14-27
         s.wi = -wo; s.dir = TRANSMIT;
         s.bxdf = gray(1.0f) / spt_abs(wo.z);
@@ -716,6 +807,24 @@ float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi) {
     case SPT_BXDF_SPECULAR_DIELECTRIC: {  // specular_dielectric.rs:74-82
         float reflect_pdf = luminance(mat_fresnel(mt, wo, v3(0, 0, 1)));
         return (wo.z * wi.z >= 0.0f) ? reflect_pdf : 1.0f - reflect_pdf;
+    }
+    case SPT_BXDF_MICROFACET_PLASTIC:
+    case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:81-99, specular_plastic.rs:65-80
+        if (!(wo.z * wi.z >= 0.0f)) return 1.0f;
+        Color fresnel_macro = plastic_fresnel(mt, wo, v3(0, 0, 1));
+        float specular_weight = luminance(fresnel_macro);
+        float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * substrate_reflectance(mt));
+        float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
+        float specular_pdf;
+        if (mt.bxdf == SPT_BXDF_MICROFACET_PLASTIC) {
+            Vec3 half = half_from_reflect(wo, wi);
+            float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+            specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        } else {
+            specular_pdf = reflect_pdf;
+        }
+        float sub_pdf = (1.0f - reflect_pdf) * substrate_pdf(mt, wo, wi);
+        return specular_pdf + sub_pdf;
     }
     default:  // specular conductor / pseudo
         return 1.0f;
@@ -763,6 +872,21 @@ Color bxdf_eval(const spt_material& mt, Vec3 wo, Vec3 wi) {
             }
         }
         return gray(0.0f);
+    }
+    case SPT_BXDF_MICROFACET_PLASTIC: {  // microfacet_plastic.rs:101-118
+        if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
+        Vec3 half = half_from_reflect(wo, wi);
+        Color refl = plastic_fresnel(mt, wo, half) * ndf_visible(mt, wo, wi, half);
+        Color fresnel_macro = plastic_fresnel(mt, wo, v3(0, 0, 1));
+        Color sub = (gray(1.0f) - fresnel_macro) * substrate_eval(mt, wo, wi);
+        return refl + sub;
+    }
+    case SPT_BXDF_SPECULAR_PLASTIC: {  // specular_plastic.rs:82-93 (the mirror term is NOT restricted to the mirror direction)
+        if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
+        Color fr = plastic_fresnel(mt, wo, v3(0, 0, 1));
+        Color refl = fr / spt_abs(wi.z);
+        Color sub = (gray(1.0f) - fr) * substrate_eval(mt, wo, wi);
+        return refl + sub;
     }
     default:  // pseudo.rs:32-38
         if (dot(wo, wi) < -0.999f) return gray(1.0f) / spt_abs(wi.z);

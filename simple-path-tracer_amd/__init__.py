@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 1
+SPT_ABI_VERSION = 2
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -73,7 +73,8 @@ class Instance(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("bxdf", C.c_uint32), ("c0", C.c_float * 3), ("c1", C.c_float * 3), ("ax", C.c_float),
-                ("ay", C.c_float), ("ior", C.c_float), ("pad", C.c_float * 2)]
+                ("ay", C.c_float), ("ior", C.c_float), ("c2", C.c_float * 3), ("fresnel", C.c_uint32),
+                ("substrate", C.c_uint32), ("pad", C.c_float)]
 
 
 class Surface(C.Structure):

@@ -234,12 +234,13 @@ SPT_DEV f3 ggx_vndf_sample(f3 ve, float ax, float ay, float r0, float r1, float*
 // ---- Bxdf over a POD material
 struct DMat {
     uint32_t bxdf;
-    f3 c0, c1;
+    f3 c0, c1, c2;
     float ax, ay, ior;
+    uint32_t fresnel, substrate;
 };
 SPT_DEV DMat load_material(const DScene& sc, uint32_t m) {
-    const float4* p = reinterpret_cast<const float4*>(sc.materials + m);
-    float4 a = p[0], b = p[1], c = p[2];
+    const float4* p = reinterpret_cast<const float4*>(sc.materials + m);   // 64-byte records
+    float4 a = p[0], b = p[1], c = p[2], e = p[3];
     DMat d;
     d.bxdf = __float_as_uint(a.x);
     d.c0 = mk3(a.y, a.z, a.w);
@@ -247,6 +248,9 @@ SPT_DEV DMat load_material(const DScene& sc, uint32_t m) {
     d.ax = b.w;
     d.ay = c.x;
     d.ior = c.y;
+    d.c2 = mk3(c.z, c.w, e.x);
+    d.fresnel = __float_as_uint(e.y);
+    d.substrate = __float_as_uint(e.z);
     return d;
 }
 SPT_DEV bool mat_is_delta(const DMat& m) {
@@ -255,6 +259,19 @@ SPT_DEV bool mat_is_delta(const DMat& m) {
 SPT_DEV f3 mat_fresnel(const DMat& m, f3 i, f3 n) {  // fresnel.rs:29-59
     if (m.bxdf == SPT_BXDF_MICROFACET_CONDUCTOR || m.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR) return fresnel_conductor_n(m.c0, m.c1, i, n);
     return gray(fresnel_n(m.ior, i, n));
+}
+// plastic lobes: SchlickFresnel / DielectricFresnel (fresnel.rs:19-59), Lambert / Diffuse substrate
+// (substrate.rs:29-45, 139-180)
+SPT_DEV float pow5(float x) { return x * x * x * x * x; }
+SPT_DEV f3 plastic_fresnel(const DMat& m, f3 i, f3 n) {
+    if (m.fresnel == SPT_FRESNEL_SCHLICK) return m.c1 + (gray(1.0f) - m.c1) * pow5(1.0f - dot(i, n));
+    return gray(fresnel_n(m.ior, i, n));
+}
+SPT_DEV float substrate_pdf(f3 wo, f3 wi) { return (wo.z * wi.z >= 0.0f) ? spt_abs(wi.z) * SPT_FRAC_1_PI : 1.0f; }
+SPT_DEV f3 substrate_eval(const DMat& m, f3 wo, f3 wi) {
+    if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
+    if (m.substrate == SPT_SUBSTRATE_DIFFUSE) return m.c2 * (1.0f - fresnel_n(m.ior, wi, mk3(0, 0, 1)));
+    return m.c0 * SPT_FRAC_1_PI;
 }
 SPT_DEV float ndf_visible(const DMat& m, f3 wo, f3 wi, f3 h) {  // microfacet.rs:47-53
     return ggx_ndf_aniso(h, m.ax, m.ay) * smith_visible_aniso(wo, wi, m.ax, m.ay);
@@ -348,6 +365,65 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng) {
         }
         break;
     }
+    case SPT_BXDF_MICROFACET_PLASTIC:
+    case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:26-79, specular_plastic.rs:19-63
+        const bool rough = m.bxdf == SPT_BXDF_MICROFACET_PLASTIC;
+        f3 fresnel_macro = plastic_fresnel(m, wo, mk3(0, 0, 1));
+        float specular_weight = luminance(fresnel_macro);
+        float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * m.c0);
+        float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
+        if (rng.next() < reflect_pdf) {
+            f3 wi, specular_bxdf;
+            float specular_pdf;
+            if (rough) {
+                float r0 = rng.next(), r1 = rng.next(), half_pdf;
+                f3 half = ggx_vndf_sample(wo, m.ax, m.ay, r0, r1, &half_pdf);
+                f3 fr = plastic_fresnel(m, wo, half);
+                wi = reflect_n(wo, half);
+                specular_bxdf = fr * ndf_visible(m, wo, wi, half);
+                specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+            } else {
+                wi = reflect_z(wo);
+                specular_bxdf = crcp(fresnel_macro, spt_abs(wi.z));
+                specular_pdf = reflect_pdf;
+            }
+            f3 substrate_bxdf = (gray(1.0f) - fresnel_macro) * substrate_eval(m, wo, wi);
+            float sub_pdf = (1.0f - reflect_pdf) * substrate_pdf(wo, wi);
+            s.wi = wi;
+            s.f = specular_bxdf + substrate_bxdf;
+            s.pdf = specular_pdf + sub_pdf;
+        } else {
+            float rx = rng.next(), ry = rng.next();
+            float phi = rx * 2.0f * SPT_PI;
+            float sp, cp;
+            spt_sincos(phi, &sp, &cp);
+            float sin_theta = spt_sqrt(ry);
+            float cos_theta = spt_sqrt(1.0f - ry);
+            f3 wi = mk3(sin_theta * cp, sin_theta * sp, cos_theta);
+            if (wo.z < 0.0f) wi.z = -wi.z;
+            f3 samp_bxdf;
+            if (m.substrate == SPT_SUBSTRATE_DIFFUSE) samp_bxdf = m.c2 * (1.0f - fresnel_n(m.ior, wi, mk3(0, 0, 1)));
+            else samp_bxdf = m.c0 * SPT_FRAC_1_PI;
+            float samp_pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
+            float sub_pdf = (1.0f - reflect_pdf) * samp_pdf;
+            f3 substrate_bxdf = (gray(1.0f) - fresnel_macro) * samp_bxdf;
+            f3 specular_bxdf;
+            float specular_pdf;
+            if (rough) {
+                f3 half = half_from_reflect(wo, wi);
+                float half_pdf = ggx_vndf_pdf(half, wo, m.ax, m.ay);
+                specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
+                specular_bxdf = plastic_fresnel(m, wo, half) * ndf_visible(m, wo, wi, half);
+            } else {
+                specular_pdf = reflect_pdf;
+                specular_bxdf = crcp(fresnel_macro, spt_abs(wi.z));
+            }
+            s.wi = wi;
+            s.f = substrate_bxdf + specular_bxdf;
+            s.pdf = sub_pdf + specular_pdf;
+        }
+        break;
+    }
     default: {  // pseudo.rs:14-27
         s.wi = -wo;
         s.f = crcp(gray(1.0f), spt_abs(wo.z));
@@ -388,6 +464,22 @@ SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi) {
     case SPT_BXDF_SPECULAR_DIELECTRIC: {  // specular_dielectric.rs:74-82
         float reflect_pdf = luminance(mat_fresnel(m, wo, mk3(0, 0, 1)));
         return (wo.z * wi.z >= 0.0f) ? reflect_pdf : 1.0f - reflect_pdf;
+    }
+    case SPT_BXDF_MICROFACET_PLASTIC:
+    case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:81-99, specular_plastic.rs:65-80
+        if (!(wo.z * wi.z >= 0.0f)) return 1.0f;
+        f3 fresnel_macro = plastic_fresnel(m, wo, mk3(0, 0, 1));
+        float specular_weight = luminance(fresnel_macro);
+        float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * m.c0);
+        float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
+        float specular_pdf;
+        if (m.bxdf == SPT_BXDF_MICROFACET_PLASTIC) {
+            f3 half = half_from_reflect(wo, wi);
+            specular_pdf = reflect_pdf * ggx_vndf_pdf(half, wo, m.ax, m.ay) / (4.0f * spt_abs(dot(wo, half)));
+        } else {
+            specular_pdf = reflect_pdf;
+        }
+        return specular_pdf + (1.0f - reflect_pdf) * substrate_pdf(wo, wi);
     }
     default:
         return 1.0f;
@@ -432,6 +524,18 @@ SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi) {
             return crcp((gray(1.0f) - fr) * (ior_ratio * ior_ratio), spt_abs(wi.z));
         }
         return gray(0.0f);
+    }
+    case SPT_BXDF_MICROFACET_PLASTIC: {  // microfacet_plastic.rs:101-118
+        if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
+        f3 half = half_from_reflect(wo, wi);
+        f3 refl = plastic_fresnel(m, wo, half) * ndf_visible(m, wo, wi, half);
+        f3 sub = (gray(1.0f) - plastic_fresnel(m, wo, mk3(0, 0, 1))) * substrate_eval(m, wo, wi);
+        return refl + sub;
+    }
+    case SPT_BXDF_SPECULAR_PLASTIC: {  // specular_plastic.rs:82-93
+        if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
+        f3 fr = plastic_fresnel(m, wo, mk3(0, 0, 1));
+        return crcp(fr, spt_abs(wi.z)) + (gray(1.0f) - fr) * substrate_eval(m, wo, wi);
     }
     default:  // pseudo.rs:32-38
         if (dot(wo, wi) < -0.999f) return crcp(gray(1.0f), spt_abs(wi.z));

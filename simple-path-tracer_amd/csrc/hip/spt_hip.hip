@@ -228,7 +228,7 @@ void validate(const spt_scene_desc& s) {
         if (s.surfaces[i].inside_medium >= 254) fail(SPT_ERR_UNSUPPORTED, "scene desc: more than 254 mediums");
     }
     for (uint32_t i = 0; i < s.n_materials; ++i)
-        if (s.materials[i].bxdf > SPT_BXDF_PSEUDO) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown bxdf tag");
+        if (s.materials[i].bxdf > SPT_BXDF_SPECULAR_PLASTIC) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown bxdf tag");
     for (uint32_t i = 0; i < s.n_lights; ++i) {
         const spt_light& l = s.lights[i];
         if (l.type > SPT_LIGHT_ENV) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown light type");

@@ -175,6 +175,13 @@ class Params {
 
 float luminance(V3 c) { return 0.299f * c.x + 0.587f * c.y + 0.114f * c.z; }
 
+float fresnel_moment1(float eta) {  // src/bxdf/util.rs:123-134
+    float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
+    if (eta < 1.0f)
+        return 0.45966f - 1.73965f * eta + 3.37668f * eta2 - 3.904945f * eta3 + 2.49277f * eta4 - 0.68441f * eta5;
+    return -4.61686f + 11.1136f * eta - 10.4646f * eta2 + 5.11455f * eta3 - 1.27198f * eta4 + 0.12746f * eta5;
+}
+
 float srgb_to_linear(float s) {  // src/texture/srgb_tex.rs
     if (s <= 0.04045f) return s / 12.92f;
     return std::pow((s + 0.055f) / 1.055f, 2.4f);
@@ -428,8 +435,49 @@ struct SceneBuilder {
             m.bxdf = (m.ax < 0.0001f || m.ay < 0.0001f) ? SPT_BXDF_SPECULAR_DIELECTRIC : SPT_BXDF_MICROFACET_DIELECTRIC;
         } else if (ty == "pseudo") {
             m.bxdf = SPT_BXDF_PSEUDO;
-        } else if (ty == "plastic" || ty == "pbr_metallic" || ty == "pbr_specular" || ty == "pndf_conductor" ||
-                   ty == "pndf_plastic" || ty == "subsurface") {
+        } else if (ty == "plastic") {
+            // src/material/plastic.rs:49-85: roughness is NOT squared here; Diffuse substrate + DielectricFresnel
+            float int_ior = p.get_float("int_ior");
+            float ext_ior = p.get_float_or("ext_ior", 1.0f);
+            V3 albedo = texture(p.get_str("albedo"));
+            float rx, ry;
+            if (p.contains("roughness")) {
+                rx = ry = texture(p.get_str("roughness")).x;
+            } else {
+                rx = texture(p.get_str("roughness_x")).x;
+                ry = texture(p.get_str("roughness_y")).x;
+            }
+            m.ior = int_ior / ext_ior;
+            m.ax = rx; m.ay = ry;
+            m.bxdf = (rx < 0.0001f || ry < 0.0001f) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+            m.fresnel = SPT_FRESNEL_DIELECTRIC;
+            m.substrate = SPT_SUBSTRATE_DIFFUSE;
+            m.c0[0] = albedo.x; m.c0[1] = albedo.y; m.c0[2] = albedo.z;
+            // Diffuse::new (src/bxdf/substrate.rs:127-137)
+            float fdr = 2.0f * fresnel_moment1(1.0f / m.ior);
+            V3 num = albedo * 0.318309886183790671538f;
+            V3 den = ((V3{1, 1, 1} - albedo * fdr) * m.ior) * m.ior;
+            m.c2[0] = num.x / den.x; m.c2[1] = num.y / den.y; m.c2[2] = num.z / den.z;
+        } else if (ty == "pbr_metallic" || ty == "pbr_specular") {
+            // src/material/pbr_metallic.rs:76-104, pbr_specular.rs:66-92: Lambert substrate + SchlickFresnel
+            V3 diffuse, specular;
+            if (ty == "pbr_metallic") {
+                V3 base = texture(p.get_str("base_color"));
+                roughness(m.ax, m.ay);
+                float metallic = texture(p.get_str("metallic")).x;
+                specular = base * metallic + V3{0.04f, 0.04f, 0.04f} * (1.0f - metallic);
+                diffuse = base * (1.0f - metallic);
+            } else {
+                diffuse = texture(p.get_str("diffuse"));
+                specular = texture(p.get_str("specular"));
+                roughness(m.ax, m.ay);
+            }
+            m.bxdf = (m.ax < 0.0001f || m.ay < 0.0001f) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+            m.fresnel = SPT_FRESNEL_SCHLICK;
+            m.substrate = SPT_SUBSTRATE_LAMBERT;
+            m.c0[0] = diffuse.x; m.c0[1] = diffuse.y; m.c0[2] = diffuse.z;
+            m.c1[0] = specular.x; m.c1[1] = specular.y; m.c1[2] = specular.z;
+        } else if (ty == "pndf_conductor" || ty == "pndf_plastic" || ty == "subsurface") {
             throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)");
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");

@@ -17,6 +17,7 @@ CASES = [  # name, scene, camera, sampler, spp, (w, h), seed
     ("film_t_materials", "t_materials.json", "main", "random", 16, (64, 48), 1),
     ("film_t_power_is", "t_power_is.json", "top", "jittered", 16, (64, 48), 1),
     ("film_t_medium", "t_medium.json", None, "random", 16, (64, 48), 1),
+    ("film_t_plastic", "t_plastic.json", None, "random", 16, (64, 48), 1),
 ]
 
 

@@ -45,7 +45,7 @@ def test_hip_library_exports_its_header_and_has_gfx950_code():
 def test_struct_sizes_match_the_header():
     # sizes the kernels rely on for their 16-byte vector loads
     assert C.sizeof(spt.BvhNode) == 32 and C.sizeof(spt.TriPos) == 48 and C.sizeof(spt.TriAttr) == 144
-    assert C.sizeof(spt.Instance) == 192 and C.sizeof(spt.Material) == 48 and C.sizeof(spt.Surface) == 32
+    assert C.sizeof(spt.Instance) == 192 and C.sizeof(spt.Material) == 64 and C.sizeof(spt.Surface) == 32
     assert C.sizeof(spt.Light) == 64 and C.sizeof(spt.Medium) == 32 and C.sizeof(spt.Sphere) == 16
     assert spt.HIT_DTYPE.itemsize == 20 and spt.RAY_DTYPE.itemsize == 32
 

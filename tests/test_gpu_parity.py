@@ -26,7 +26,7 @@ def _scene(spt, name):
     return spt.load_scene(os.path.join(_util.SCENES, name))
 
 
-@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json"])
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json"])
 def test_trace_closest_and_any_bit_exact(spt, scene_name):
     sc = _scene(spt, scene_name)
     rays = _util.random_rays(sc, 200_000, seed=11)
@@ -88,6 +88,7 @@ def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
     ("t_materials.json", "top", "jittered"),     #   dir/point/spot/shape lights, uniform light sampler, TLAS
     ("t_power_is.json", "main", "recurrence"),   # power_is alias-table sampler, colour environment, group aggregate
     ("t_medium.json", None, "random"),           # homogeneous media (HG g=0.3 and isotropic), pseudo boundary, area light
+    ("t_plastic.json", None, "random"),          # plastic (rough/smooth/aniso), pbr_metallic, pbr_specular
 ])
 def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     sc = _scene(spt, scene_name)

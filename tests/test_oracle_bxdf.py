@@ -224,3 +224,86 @@ def test_white_furnace_closed_lambert_box(tmp_path):
     film, _ = _util.oracle_render(scene, r, 32, 32)
     expect = le * (1 - rho ** 8) / (1 - rho)      # emission seen at depths 0..7
     assert abs(film.mean() - expect) / expect < 0.02
+
+
+# ---------------------------------------------------------------- plastic / PBR stack
+MF_PLASTIC, SP_PLASTIC = 6, 7
+
+
+def plastic(bxdf, fresnel, substrate, c0, c1=(0, 0, 0), c2=(0, 0, 0), ax=0.0, ay=0.0, ior=1.0):
+    m = mat(bxdf, c0=c0, c1=c1, ax=ax, ay=ay, ior=ior)
+    m.c2[:] = c2
+    m.fresnel, m.substrate = fresnel, substrate
+    return m
+
+
+def _diffuse_c2(albedo, ior):
+    """Diffuse::new (substrate.rs:127-137) in float64."""
+    eta = 1.0 / ior
+    e = [eta ** k for k in range(6)]
+    fm1 = (0.45966 - 1.73965 * e[1] + 3.37668 * e[2] - 3.904945 * e[3] + 2.49277 * e[4] - 0.68441 * e[5]) if eta < 1 else \
+        (-4.61686 + 11.1136 * e[1] - 10.4646 * e[2] + 5.11455 * e[3] - 1.27198 * e[4] + 0.12746 * e[5])
+    a = np.asarray(albedo, float)
+    return a / np.pi / ((1 - a * 2 * fm1) * ior * ior)
+
+
+@pytest.mark.parametrize("kind", ["plastic_rough", "plastic_smooth", "pbr_rough", "pbr_smooth"])
+def test_plastic_sample_pdf_eval_consistent_and_energy_bounded(kind):
+    albedo = (0.2, 0.45, 0.7)
+    if kind.startswith("plastic"):
+        m = plastic(MF_PLASTIC if kind.endswith("rough") else SP_PLASTIC, 0, 1, albedo, c2=_diffuse_c2(albedo, 1.5), ax=0.2, ay=0.1, ior=1.5)
+    else:
+        m = plastic(MF_PLASTIC if kind.endswith("rough") else SP_PLASTIC, 1, 0, albedo, c1=(0.04, 0.04, 0.04), ax=0.16, ay=0.16)
+    n_refl = 0
+    for k in range(400):
+        wi, f, pdf, dr = sample(m, WO, lib.oracle_rng_state(17, k, 4))
+        assert dr == 0 and abs(np.linalg.norm(wi) - 1) < 1e-4 and pdf > 0
+        n_refl += wi[2] > 0
+        if wi[2] <= 1e-3:
+            continue      # a microfacet reflection can dip below the horizon; pdf()/bxdf() then see "other side"
+        f2, pdf2 = evaluate(m, WO, wi)
+        assert np.all(f >= 0)
+        assert abs(pdf - pdf2) <= 3e-3 * max(pdf, 1e-3)        # sample() and pdf() agree
+        assert np.allclose(f, f2, rtol=3e-3, atol=1e-6)        # sample() and bxdf() agree
+    assert n_refl >= 380                                         # reflect-only lobes, same side as wo
+    f, p = evaluate(m, WO, (0.0, 0.6, -0.8))
+    assert np.all(f == 0) and p == 1.0                           # other hemisphere: bxdf 0, pdf 1 (quirk Q15)
+    if kind.endswith("rough"):
+        d, dw = sphere_dirs(500, 1000)
+        up = d[d[:, 2] > 0][::9]
+        pd = np.array([evaluate(m, WO, w)[1] for w in up])
+        assert 0.9 < pd.sum() * dw * 9 <= 1.03                   # mixture pdf integrates to ~1
+        alb = np.array([evaluate(m, WO, w)[0] * w[2] for w in up]).sum(0) * dw * 9
+        assert np.all(alb < 1.02) and np.all(alb > 0.05)         # energy conserving
+
+
+def test_schlick_fresnel_and_diffuse_substrate_formulas():
+    # Schlick: r0 + (1 - r0)(1 - cos)^5 with cos = wo.n (fresnel.rs:49-52); at normal incidence F = r0
+    m = plastic(SP_PLASTIC, 1, 0, (0.5, 0.5, 0.5), c1=(0.04, 0.5, 0.9))
+    wi = np.array([0.0, 0.0, 1.0])
+    f, _ = evaluate(m, (0.0, 0.0, 1.0), wi)
+    r0 = np.array([0.04, 0.5, 0.9])
+    assert np.allclose(f, r0 / 1.0 + (1 - r0) * 0.5 / np.pi, rtol=1e-5)   # mirror term fr/|z| + (1-fr) rho/pi
+    # Diffuse substrate: (1 - F(wi)) * bxdf_wo_fresnel with the dielectric coat (substrate.rs:139-171)
+    albedo, ior = (0.2, 0.45, 0.7), 1.5
+    c2 = _diffuse_c2(albedo, ior)
+    m = plastic(SP_PLASTIC, 0, 1, albedo, c2=c2, ior=ior)
+    wo = np.array([0.0, 0.0, 1.0])
+    wi = np.array([0.6, 0.0, 0.8])
+    F = lambda v: lib.oracle_fresnel_dielectric(ior, V3(*v), V3(0, 0, 1))
+    f, _ = evaluate(m, wo, wi)
+    assert np.allclose(f, F(wo) / 0.8 + (1 - F(wo)) * (1 - F(wi)) * c2, rtol=2e-5)
+
+
+def test_host_loader_resolves_plastic_and_pbr_materials():
+    sc = spt.load_scene(os.path.join(_util.SCENES, "t_plastic.json"))
+    mats = sc.array("materials")[-6:]
+    assert mats["bxdf"].tolist() == [6, 7, 6, 6, 7, 6]
+    assert mats["fresnel"].tolist() == [0, 0, 0, 1, 1, 1] and mats["substrate"].tolist() == [1, 1, 1, 0, 0, 0]
+    assert np.allclose([mats["ax"][0], mats["ay"][2]], [0.15, 0.15])          # plastic: roughness NOT squared (plastic.rs:66-67)
+    assert np.allclose([mats["ax"][3], mats["ay"][5]], [0.16, 0.16])          # pbr: roughness^2
+    assert np.allclose(mats["c2"][0], _diffuse_c2((0.1, 0.25, 0.7), 1.5), rtol=1e-5)
+    # pbr_metallic: specular = m*base + (1-m)*0.04, diffuse = base*(1-m)
+    base = np.array([0.9, 0.45, 0.1])
+    assert np.allclose(mats["c1"][3], 0.9 * base + 0.1 * 0.04, rtol=1e-5) and np.allclose(mats["c0"][3], base * 0.1, rtol=1e-4)
+    assert np.allclose(mats["c1"][4], [0.04] * 3) and np.allclose(mats["c0"][4], base)
