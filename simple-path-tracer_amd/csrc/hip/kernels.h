@@ -284,12 +284,9 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             bool alive = true;       // false: path ended without the RR / depth tail (`break`)
             bool scattered = false;  // a new ray was produced (tail applies)
 
-            DInstance in;
             DInter it;
-            if (does_hit) {
-                in = load_instance(sc, (uint32_t)h.inst);
-                it = reconstruct_hit(sc, in, ray, h);
-            }
+            it.prim_type = 0u; it.prim_id = 0u;
+            if (does_hit) it = reconstruct_hit(sc, ray, h);
 
             if (!kSimple && medium >= 0) {  // pt.rs:56-96
                 const spt_medium& md = sc.mediums[medium];
@@ -317,12 +314,12 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         float transported = ls.dist;
                         bool probe_hit = false;
                         float probe_t = 0.0f;
-                        if (does_hit && in.prim_type == SPT_PRIM_MESH) {
+                        if (does_hit && it.prim_type == SPT_PRIM_MESH) {
                             float t, v, w;
                             if (tri_test(sc.tri_pos, (uint32_t)h.prim, sr, &t, &v, &w) && t > sr.t_min && t < probe_max) { probe_hit = true; probe_t = t; }
                         } else if (does_hit) {
                             float mn, mx;
-                            if (sphere_roots(sc.spheres[in.prim_id], sr, &mn, &mx)) {
+                            if (sphere_roots(sc.spheres[it.prim_id], sr, &mn, &mx)) {
                                 float t = (mn < sr.t_min) ? mx : mn;
                                 if (sr.t_min < t && t < probe_max) { probe_hit = true; probe_t = t; }
                             }
@@ -385,7 +382,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     f3 le = mk3(sf.emissive);
                     if (!kSimple && luminance(le) > 0.0f) {
                         float weight = 1.0f;
-                        if (depth != 0u) weight = power_heuristic(last_pdf, pdf_shape_light(sc, in, sflags, lsi, it, h.prim));
+                        if (depth != 0u) weight = power_heuristic(last_pdf, pdf_shape_light(sc, (uint32_t)h.inst, sflags, lsi, it, h.prim));
                         rad_add(rc, slot, (thr * le) * weight);
                     }
                     f3 wo = coord.to_local(-ray.d);

@@ -69,7 +69,8 @@ SPT_DEV DInstance load_instance(const DScene& sc, uint32_t inst) {
 
 // Rebuild the shading inputs of a recorded hit (t, instance, prim, v, w):
 // triangle.rs:188-212 or sphere.rs:64-83, then instance.rs:97-104.
-SPT_DEV DInter reconstruct_hit(const DScene& sc, const DInstance& in, const DRay& ray, const DHit& h) {
+SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h) {
+    const DInstance in = load_instance(sc, (uint32_t)h.inst);
     DInter it;
     f3 n, tg, bt;
     if (in.prim_type == SPT_PRIM_SPHERE) {
@@ -644,16 +645,21 @@ SPT_DEV void instance_sample(const DScene& sc, const DInstance& in, DRng& rng, f
 }
 
 // Instance::pdf (instance.rs:131-141) over Triangle::pdf / Sphere::pdf
-SPT_DEV float instance_pdf(const DScene& sc, const DInstance& in, const DInter& it, int32_t prim) {
-    f3 tangent = xf_vector(in.inv, it.tangent);
-    f3 bitangent = xf_vector(in.inv, it.bitangent);
+SPT_DEV float instance_pdf(const DScene& sc, uint32_t inst, const DInter& it, int32_t prim) {
+    // re-read the 3 float4 of trans_inv here instead of keeping the whole instance record live through
+    // the shading code (L1 hit; keeps k_shade<false> under the next VGPR step)
+    const float4* I = sc.instances + 12 * inst;
+    float4 m0 = I[0], m1 = I[1], m2 = I[2];
+    const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
+    f3 tangent = xf_vector(inv, it.tangent);
+    f3 bitangent = xf_vector(inv, it.bitangent);
     float original_area = length(cross(tangent, bitangent));
     float transformed_area = length(cross(it.tangent, it.bitangent));
     float prim_pdf;
-    if (in.prim_type == SPT_PRIM_SPHERE) {
+    if (it.prim_type == SPT_PRIM_SPHERE) {
         prim_pdf = 0.25f * SPT_FRAC_1_PI;
     } else {
-        uint4 mesh = sc.meshes[in.prim_id];
+        uint4 mesh = sc.meshes[it.prim_id];
         f3 p0 = mk3(sc.tri_pos[3 * prim]), p1 = mk3(sc.tri_pos[3 * prim + 1]), p2 = mk3(sc.tri_pos[3 * prim + 2]);
         float area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
         prim_pdf = (1.0f / spt_max(area, 0.001f)) / (float)mesh.w;
@@ -747,8 +753,8 @@ SPT_DEV bool sample_light(const DScene& sc, f3 position, DRng& rng, DLightSample
     return true;
 }
 // pdf_shape_light (uniform.rs:43-68, power_is.rs:61-88)
-SPT_DEV float pdf_shape_light(const DScene& sc, const DInstance& in, uint32_t surf_flags, f3 position, const DInter& it, int32_t prim) {
-    float primitive_pdf = instance_pdf(sc, in, it, prim);
+SPT_DEV float pdf_shape_light(const DScene& sc, uint32_t inst, uint32_t surf_flags, f3 position, const DInter& it, int32_t prim) {
+    float primitive_pdf = instance_pdf(sc, inst, it, prim);
     f3 light_vec = it.position - position;
     float dist_sqr = dot(light_vec, light_vec);
     f3 light_dir = light_vec / spt_sqrt(dist_sqr);
@@ -760,7 +766,7 @@ SPT_DEV float pdf_shape_light(const DScene& sc, const DInstance& in, uint32_t su
         if (!(cosv > 0.0f)) cosv = 1.0f;
     }
     float local_pdf = primitive_pdf * dist_sqr / spt_max(cosv, 0.00001f);
-    if (sc.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) return local_pdf * sc.light_props[in.light];
+    if (sc.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) return local_pdf * sc.light_props[it.light];
     return local_pdf * (1.0f / (float)sc.n_lights);
 }
 SPT_DEV float pdf_env_light(const DScene& sc) {  // uniform.rs:70-76, power_is.rs:90-96
