@@ -42,6 +42,7 @@ def load_pkg():
 
 # record sizes of the queue layouts in simple-path-tracer_amd/csrc/hip/kernels.h (bytes)
 S_PATH, S_HIT, S_SHADOW, S_RAD = 72, 20, 48, 12
+S_PATH0 = 16  # compact bounce-0 record: direction + slot
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -176,8 +177,8 @@ def main():
         # queue records written/read once + radiance-slot / film read-modify-writes; scene geometry of
         # this workload (< 2 KB) is LDS-resident and counted as 0 ("count it once").
         alg = {
-            "primary": hits0 * (S_PATH + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
-            "shade": verts * (S_PATH + S_HIT) + seg_s * S_SHADOW + ext * S_PATH,
+            "primary": hits0 * (S_PATH0 + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
+            "shade": hits0 * (S_PATH0 + S_HIT) + (verts - hits0) * (S_PATH + S_HIT) + seg_s * S_SHADOW + ext * S_PATH,
             "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
             "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
             "resolve": hits0 * S_RAD + passes * n_pix * 2 * S_RAD,

@@ -106,6 +106,32 @@ SPT_DEV uint32_t wave_push(bool pred, uint32_t* counter) {
     return base + (uint32_t)__popcll(mask & lt);
 }
 
+// The same append in two halves, so the atomic's round trip (~1-2 us to the L2 atomic unit and back)
+// overlaps independent work: issue() starts the atomicAdd and returns at once (the returned value is
+// only read in finish(), and the compiler places the s_waitcnt at that first use).
+struct PendingPush {
+    unsigned long long mask;
+    uint32_t base_raw, leader;
+};
+SPT_DEV PendingPush wave_push_issue(bool pred, uint32_t* counter) {
+    PendingPush p;
+    p.mask = __ballot(pred);
+    p.base_raw = 0u;
+    p.leader = 0u;
+    if (p.mask != 0ull) {
+        p.leader = (uint32_t)__ffsll((long long)p.mask) - 1u;
+        if (lane_id() == p.leader) p.base_raw = atomicAdd(counter, (uint32_t)__popcll(p.mask));
+    }
+    return p;
+}
+SPT_DEV uint32_t wave_push_finish(const PendingPush& p) {
+    if (p.mask == 0ull) return 0u;
+    const uint32_t lane = lane_id();
+    const uint32_t base = (uint32_t)__shfl((int)p.base_raw, (int)p.leader, 64);
+    const unsigned long long lt = (lane == 0u) ? 0ull : (~0ull >> (64u - lane));
+    return base + (uint32_t)__popcll(p.mask & lt);
+}
+
 // PerspectiveCamera::generate_ray (camera/perspective.rs:40-47)
 SPT_DEV DRay camera_ray(const DCamera& c, float x, float y) {
     DRay r;
@@ -167,6 +193,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     if (valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
     uint32_t first = rc.pass_samples;
     const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    uint32_t* hit_counter = q_count(rc.counts, 0, Q_HIT, shard);
     for (uint32_t s = 0; s < rc.pass_samples; ++s) {
         const uint32_t gs = rc.pass_first + s;
         DRng rng;
@@ -215,10 +242,14 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
             if (first == rc.pass_samples) first = s;
             rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
         }
-        uint32_t slot = shard * rc.shard_cap + wave_push(hit, q_count(rc.counts, 0, Q_HIT, shard));
+        // (deferring this append by one iteration to overlap the atomic with the next sample was
+        //  MEASURED slower: +16 VGPRs of pending state drop the kernel from 4 to 3 waves per SIMD)
+        const uint32_t slot = shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {
-            if (lazy_rng) rng.s = spt_rng_seed(rc.seed, pixel, gs);
-            store_path(rc.qa, slot, ray, 0.0f, gray(1.0f), (uint32_t)ri, mk3(0, 0, 0), pack_meta(0u, -1), rng);
+            // bounce-0 records are compact: origin (eye), t_min, throughput (1), last_pdf (0), depth, medium and
+            // the RNG stream (a function of pixel and sample = of the slot) are constants that k_shade<.., true>
+            // rebuilds, so only (direction, slot) and the hit record travel: 36 B instead of 92 B per hit
+            rc.qa.d_pdf[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float((uint32_t)ri));
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
             rc.hits.inst[slot] = h.inst;
         }
@@ -243,7 +274,8 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // materials, delta lights, no emission, no environment, no media.  The general code path is
 // identical arithmetic; the specialisation only removes branches that cannot be taken, which
 // cuts the kernel from 226 to far fewer VGPRs (more waves per SIMD to hide queue latency).
-template <bool kSimple>
+// kFirst: bounce 0, whose queue holds the compact records written by k_primary.
+template <bool kSimple, bool kFirst>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
@@ -263,20 +295,43 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
         DRng rng;
         rng.s.state = 0ull;
         if (active) {
-            float4 a = rc.qa.o_tmin[idx], b = rc.qa.d_pdf[idx], c = rc.qa.thr_slot[idx], d = rc.qa.lsi_meta[idx];
-            uint2 rs = rc.qa.rng[idx];
             float4 hv = rc.hits.t_v_w_prim[idx];
             DRay ray;
-            ray.o = mk3(a); ray.t_min = a.w;
-            ray.d = mk3(b);
-            float last_pdf = b.w;
-            thr = mk3(c);
-            slot = __float_as_uint(c.w);
-            lsi = mk3(d);
-            uint32_t meta = __float_as_uint(d.w);
-            depth = meta & 0xffu;
-            medium = (int32_t)(meta >> 8) - 1;
-            rng.s.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+            float last_pdf;
+            if (kFirst) {
+                // rebuild the constants of a camera path from the slot (see k_primary)
+                const float4 b = rc.qa.d_pdf[idx];
+                slot = __float_as_uint(b.w);
+                const uint32_t s_local = slot / rc.n_pixels, lp = slot - s_local * rc.n_pixels;
+                const uint32_t row_local = lp / rc.width, col = lp - row_local * rc.width;
+                const uint32_t strip = row_local / rc.strip_rows;
+                const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
+                rng.s = spt_rng_seed(rc.seed, j * rc.width + col, rc.pass_first + s_local);
+                if (rc.sampler != SPT_SAMPLER_RECURRENCE) {  // the pixel offsets were the first two draws
+                    (void)rng.next();
+                    (void)rng.next();
+                }
+                ray.o = rc.cam.eye; ray.t_min = kTMinEps;
+                ray.d = mk3(b);
+                last_pdf = 0.0f;
+                thr = gray(1.0f);
+                lsi = mk3(0, 0, 0);
+                depth = 0u;
+                medium = -1;
+            } else {
+                float4 a = rc.qa.o_tmin[idx], b = rc.qa.d_pdf[idx], c = rc.qa.thr_slot[idx], d = rc.qa.lsi_meta[idx];
+                uint2 rs = rc.qa.rng[idx];
+                ray.o = mk3(a); ray.t_min = a.w;
+                ray.d = mk3(b);
+                last_pdf = b.w;
+                thr = mk3(c);
+                slot = __float_as_uint(c.w);
+                lsi = mk3(d);
+                uint32_t meta = __float_as_uint(d.w);
+                depth = meta & 0xffu;
+                medium = (int32_t)(meta >> 8) - 1;
+                rng.s.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+            }
             DHit h;
             h.t = hv.x; h.v = hv.y; h.w = hv.z; h.prim = __float_as_int(hv.w);
             h.inst = rc.hits.inst[idx];
@@ -438,13 +493,16 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 }
             }
         }
-        uint32_t ss = qbase + wave_push(want_shadow, shadow_count);
+        // both reservations in flight together: one atomic round trip per iteration instead of two
+        const PendingPush ps = wave_push_issue(want_shadow, shadow_count);
+        const PendingPush pe = wave_push_issue(want_ext, ext_count);
+        uint32_t ss = qbase + wave_push_finish(ps);
         if (want_shadow) {
             rc.shadow.o_tmin[ss] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.t_min);
             rc.shadow.d_tmax[ss] = make_float4(shadow_ray.d.x, shadow_ray.d.y, shadow_ray.d.z, shadow_tmax);
             rc.shadow.contrib_slot[ss] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
         }
-        uint32_t es = qbase + wave_push(want_ext, ext_count);
+        uint32_t es = qbase + wave_push_finish(pe);
         if (want_ext) store_path(rc.qb, es, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
     }
 }

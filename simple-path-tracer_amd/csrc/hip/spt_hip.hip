@@ -617,10 +617,13 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             end();
             for (uint32_t b = 0; b < p.max_depth; ++b) {
                 begin(SPT_K_SHADE);
-                if (sc->simple)
-                    hipLaunchKernelGGL(k_shade<true>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                else
-                    hipLaunchKernelGGL(k_shade<false>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                if (sc->simple) {
+                    if (b == 0) hipLaunchKernelGGL((k_shade<true, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    else hipLaunchKernelGGL((k_shade<true, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                } else {
+                    if (b == 0) hipLaunchKernelGGL((k_shade<false, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    else hipLaunchKernelGGL((k_shade<false, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                }
                 end();
                 begin(SPT_K_SHADOW);
                 if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
