@@ -31,6 +31,7 @@
 #pragma once
 #include "shading.h"
 
+
 struct DCamera {
     f3 eye, forward, up, right;
     float half_cot;

@@ -126,3 +126,28 @@ def test_render_error_paths(spt):
     r2 = spt.PathTracer(max_depth=300, spp=4)
     with pytest.raises(spt.SptError):
         r2.render_shard(sc, spt.OutputConfig(16, 16))
+
+
+def test_full_size_cfg2_properties(spt):
+    """BASELINE configs[1] at full size (1024x1024 @ 256 spp, 268 M samples) through properties that do not
+    need the oracle: closed-form face radiances, the reference's u8 values, determinism."""
+    sc = _scene(spt, "cfg2_cube.json")
+    r = spt.load_renderer(os.path.join(_util.SCENES, "pt.json"), seed=1)
+    assert (r.spp, r.max_depth) == (256, 8)
+    film = r.render_shard(sc, spt.OutputConfig(1024, 1024))
+    assert r.last_stats.samples == 1024 * 1024 * 256
+    l = np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0)
+    c, s = np.cos(np.radians(60.0)), np.sin(np.radians(60.0))
+    lum = [5.0 / np.pi * max(float(np.dot(n, l)), 0.0) for n in ([s, 0.0, c], [-c, 0.0, s])]
+    g = film[..., 0]
+    assert np.array_equal(film[..., 0], film[..., 1]) and np.array_equal(film[..., 1], film[..., 2])
+    near = lambda v: np.abs(g - v) < 3e-5
+    interior = near(0.0) | near(lum[0]) | near(lum[1])
+    assert interior.mean() > 0.99
+    assert abs(near(lum[0]).mean() + near(lum[1]).mean() - 0.1846) < 0.004
+    assert abs(float(g.mean()) - 0.11295) < 5e-4
+    assert set(np.unique(spt.film_to_rgb8(film)[interior])) == {0, 85, 255}
+    assert abs(r.last_stats.primary_hits / r.last_stats.samples - 0.1846) < 0.002
+    # same call again: bit-identical (no float atomics, no order dependence); other pass size too
+    again = r.render_shard(sc, spt.OutputConfig(1024, 1024), samples_per_pass=37)
+    assert np.array_equal(film.view(np.uint32), again.view(np.uint32))
