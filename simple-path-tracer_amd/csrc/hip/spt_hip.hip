@@ -159,6 +159,120 @@ uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4
     return super;
 }
 
+// Collapse a 2-ary tree of 32-byte nodes into compressed 4-wide nodes (see trace.h).  Returns the ref of
+// the root (node index in `out` / 4, or a leaf ref).  Children boxes are quantised OUTWARD and verified
+// with exactly the f32 decode arithmetic of node4_test.
+// `stack_need` receives the worst-case number of simultaneously pending entries of a near-first walk: a
+// node with n children leaves n - 1 of them pending while the first is descended, in whatever order.
+uint32_t build_n4(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>& out, uint32_t* stack_need, const char* what) {
+    *stack_need = 0;
+    auto leaf_ref = [&](const spt_bvh_node& nd) -> uint32_t {
+        uint32_t cnt = nd.b & ~SPT_LEAF_FLAG;
+        if (cnt > 15u) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": BVH leaf with more than 15 items");
+        if (nd.a >= (1u << 27)) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": more than 2^27 items");
+        return kLeaf | (cnt << 27) | nd.a;
+    };
+    auto area = [&](const spt_bvh_node& nd) {
+        float dx = nd.bmax[0] - nd.bmin[0], dy = nd.bmax[1] - nd.bmin[1], dz = nd.bmax[2] - nd.bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    if (nodes[root].b & SPT_LEAF_FLAG) return leaf_ref(nodes[root]);
+    struct Item { uint32_t node32, n4; };
+    std::vector<Item> st;
+    auto alloc = [&]() -> uint32_t {
+        uint32_t i = (uint32_t)(out.size() / 4);
+        out.resize(out.size() + 4, make_float4(0, 0, 0, 0));
+        return i;
+    };
+    const uint32_t root_n4 = alloc();
+    st.push_back(Item{root, root_n4});
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        const spt_bvh_node& par = nodes[it.node32];
+        // gather up to 4 children by repeatedly opening the inner child with the largest box
+        uint32_t ch[4] = {par.a, par.b, 0, 0};
+        uint32_t n = 2;
+        while (n < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (uint32_t k = 0; k < n; ++k)
+                if (!(nodes[ch[k]].b & SPT_LEAF_FLAG) && area(nodes[ch[k]]) > best_area) { best_area = area(nodes[ch[k]]); best = (int)k; }
+            if (best < 0) break;
+            const spt_bvh_node& open = nodes[ch[best]];
+            ch[best] = open.a;
+            ch[n++] = open.b;
+        }
+        // quantisation frame: p = parent min, scale = 2^e >= extent / 254
+        uint32_t eb[3];
+        float scale[3];
+        for (int k = 0; k < 3; ++k) {
+            float ext = par.bmax[k] - par.bmin[k];
+            int e = -120;
+            if (ext > 0.0f && std::isfinite(ext)) {
+                e = (int)std::ceil(std::log2((double)ext / 254.0));
+                if (e < -120) e = -120;
+                if (e > 120) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": node extent too large to quantise");
+            }
+            eb[k] = (uint32_t)(e + 127);
+            uint32_t bits = eb[k] << 23;
+            std::memcpy(&scale[k], &bits, 4);
+        }
+        uint32_t qlo[3][4], qhi[3][4], refs[4] = {0, 0, 0, 0};
+        for (uint32_t c = 0; c < 4; ++c)
+            for (int k = 0; k < 3; ++k) { qlo[k][c] = 255u; qhi[k][c] = 0u; }   // absent child: empty box
+        for (uint32_t c = 0; c < n; ++c) {
+            const spt_bvh_node& cn = nodes[ch[c]];
+            for (int k = 0; k < 3; ++k) {
+                const float p = par.bmin[k];
+                int lo = (int)std::floor(((double)cn.bmin[k] - (double)p) / (double)scale[k]);
+                int hi = (int)std::ceil(((double)cn.bmax[k] - (double)p) / (double)scale[k]);
+                lo = std::max(0, std::min(255, lo));
+                hi = std::max(0, std::min(255, hi));
+                // verify with the device's arithmetic: p + scale * q (f32 multiply, then f32 add)
+                auto dec = [&](int q) { float m = scale[k] * (float)q; return p + m; };
+                while (lo > 0 && dec(lo) > cn.bmin[k]) --lo;
+                while (hi < 255 && dec(hi) < cn.bmax[k]) ++hi;
+                if (dec(lo) > cn.bmin[k] || dec(hi) < cn.bmax[k]) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": cannot quantise a child box conservatively");
+                qlo[k][c] = (uint32_t)lo;
+                qhi[k][c] = (uint32_t)hi;
+            }
+            if (cn.b & SPT_LEAF_FLAG) {
+                refs[c] = leaf_ref(cn);
+            } else {
+                refs[c] = alloc();
+                st.push_back(Item{ch[c], refs[c]});
+            }
+        }
+        auto pack4 = [](const uint32_t q[4]) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
+        auto as_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+        float4* f = &out[(size_t)it.n4 * 4];
+        f[0] = make_float4(par.bmin[0], par.bmin[1], par.bmin[2], as_f(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (n << 24)));
+        f[1] = make_float4(as_f(pack4(qlo[0])), as_f(pack4(qlo[1])), as_f(pack4(qlo[2])), as_f(pack4(qhi[0])));
+        f[2] = make_float4(as_f(pack4(qhi[1])), as_f(pack4(qhi[2])), as_f(refs[0]), as_f(refs[1]));
+        f[3] = make_float4(as_f(refs[2]), as_f(refs[3]), 0.0f, 0.0f);
+    }
+    // children are allocated after their parent, so one reverse sweep sees every child before its parent
+    const uint32_t end_n4 = (uint32_t)(out.size() / 4);
+    std::vector<uint32_t> need(end_n4 - root_n4, 0u);
+    for (uint32_t i = end_n4; i-- > root_n4;) {
+        const float4* f = &out[(size_t)i * 4];
+        uint32_t hdr, refs[4];
+        std::memcpy(&hdr, &f[0].w, 4);
+        std::memcpy(&refs[0], &f[2].z, 4);
+        std::memcpy(&refs[1], &f[2].w, 4);
+        std::memcpy(&refs[2], &f[3].x, 4);
+        std::memcpy(&refs[3], &f[3].y, 4);
+        const uint32_t n = hdr >> 24;
+        uint32_t deepest = 0;
+        for (uint32_t c = 0; c < n; ++c)
+            if (!(refs[c] & kLeaf)) deepest = std::max(deepest, need[refs[c] - root_n4]);
+        need[i - root_n4] = n - 1 + deepest;
+    }
+    *stack_need = need[0];
+    return root_n4;
+}
+
 }  // namespace
 
 struct spt_scene {
@@ -308,7 +422,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             // each BLAS must index triangles inside its own mesh range
             blas_depth = std::max(blas_depth, bvh_depth(s.blas_nodes, s.n_blas_nodes, s.meshes[i].root, s.n_tris, "blas"));
         }
-        // near-first traversal pushes at most one (far) child per level
+        // near-first traversal pushes at most one (far) child per 2-wide level (4-wide trees: see build_n4)
         uint32_t cap = tlas_depth + blas_depth + 2;
         if (cap > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (48 levels)");
         sc->tlas.upload(s.tlas_nodes, s.n_tlas_nodes);
@@ -362,7 +476,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         for (int i = 0; i < 3; ++i) d.env_scale[i] = s.env.scale[i];
         d.stack_cap = cap;
         {
-            // one float4 blob for everything the traversal touches
+            // one float4 blob for everything the traversal touches: [tlas | instances | meshes | spheres | blas | tri]
             std::vector<float4> blob;
             auto append = [&](const void* src, size_t bytes) {
                 uint32_t off = (uint32_t)blob.size();
@@ -371,10 +485,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 if (bytes) std::memcpy(&blob[off], src, bytes);
                 return off;
             };
-            // LDS budget of a large scene: what every ray touches first
-            constexpr uint32_t kTopNodes = 256;            // 16 KiB of BLAS top levels
-            constexpr size_t kPrefixBudget = 12u * 1024u;  // TLAS + instances + mesh records + spheres
-            std::vector<float4> wtlas, wblas;
+            std::vector<float4> wtlas;
             d.tlas_root = 0;
             for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = 0.0f; d.tlas_hi[k] = 0.0f; }
             if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) {
@@ -382,40 +493,45 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 std::memcpy(&d.tlas_root, &wtlas[(size_t)sup * 4].w, 4);      // left child of the super-root = real root
                 for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = s.tlas_nodes[0].bmin[k]; d.tlas_hi[k] = s.tlas_nodes[0].bmax[k]; }
             }
-            // small meshes first (all their nodes land in the staged prefix), the largest mesh last with
-            // its top levels breadth-first
-            std::vector<uint32_t> order(s.n_meshes);
-            for (uint32_t i = 0; i < s.n_meshes; ++i) order[i] = i;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return s.meshes[x].node_count < s.meshes[y].node_count; });
-            std::vector<float4> mesh_rec((size_t)s.n_meshes * 2, make_float4(0, 0, 0, 0));   // (root.lo, root ref) (root.hi, -)
-            uint32_t staged_nodes = 0;
-            for (uint32_t k = 0; k < s.n_meshes; ++k) {
-                const uint32_t i = order[k];
-                const uint32_t before = (uint32_t)(wblas.size() / 4);
-                const uint32_t room = before < kTopNodes ? kTopNodes - before : 0u;
-                const uint32_t sup = build_wide(s.blas_nodes, s.meshes[i].root, wblas, room, "blas");
-                const spt_bvh_node& rn = s.blas_nodes[s.meshes[i].root];
-                mesh_rec[2 * i] = make_float4(rn.bmin[0], rn.bmin[1], rn.bmin[2], wblas[(size_t)sup * 4].w);
-                mesh_rec[2 * i + 1] = make_float4(rn.bmax[0], rn.bmax[1], rn.bmax[2], 0.0f);
-                staged_nodes = std::min<uint32_t>((uint32_t)(wblas.size() / 4), kTopNodes);
-            }
-            d.o_tlas = append(wtlas.data(), wtlas.size() * 16);
-            d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
-            d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
-            d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
-            const size_t prefix_bytes = blob.size() * 16;
-            d.o_blas = append(wblas.data(), wblas.size() * 16);
-            d.o_tri = append(s.tri_pos, (size_t)s.n_tris * sizeof(spt_tri_pos));
+            // BLAS: 2-wide full-precision nodes when the whole scene fits LDS, compressed 4-wide nodes otherwise
+            auto assemble = [&](bool n4) {
+                blob.clear();
+                std::vector<float4> wblas;
+                std::vector<float4> mesh_rec((size_t)s.n_meshes * 2, make_float4(0, 0, 0, 0));   // (root.lo, root ref) (root.hi, -)
+                for (uint32_t i = 0; i < s.n_meshes; ++i) {
+                    const spt_bvh_node& rn = s.blas_nodes[s.meshes[i].root];
+                    uint32_t root_ref;
+                    if (n4) {
+                        uint32_t need = 0;
+                        root_ref = build_n4(s.blas_nodes, s.meshes[i].root, wblas, &need, "blas");
+                        if (tlas_depth + need + 2 > kLdsStack + kSpillStack)
+                            fail(SPT_ERR_UNSUPPORTED, "4-wide BVH needs more than the traversal stack (48 entries)");
+                    } else {
+                        const uint32_t sup = build_wide(s.blas_nodes, s.meshes[i].root, wblas, 0u, "blas");
+                        std::memcpy(&root_ref, &wblas[(size_t)sup * 4].w, 4);
+                    }
+                    float rf;
+                    std::memcpy(&rf, &root_ref, 4);
+                    mesh_rec[2 * i] = make_float4(rn.bmin[0], rn.bmin[1], rn.bmin[2], rf);
+                    mesh_rec[2 * i + 1] = make_float4(rn.bmax[0], rn.bmax[1], rn.bmax[2], 0.0f);
+                }
+                d.o_tlas = append(wtlas.data(), wtlas.size() * 16);
+                d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
+                d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
+                d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
+                d.o_blas = append(wblas.data(), wblas.size() * 16);
+                d.o_tri = append(s.tri_pos, (size_t)s.n_tris * sizeof(spt_tri_pos));
+            };
+            const size_t stack_bytes = (size_t)kLdsStack * 2 * kBlock * sizeof(uint32_t);   // (ref, t0) per LDS level
+            assemble(false);
+            sc->lds_geo = blob.size() * 16 <= 32u * 1024u && stack_bytes + blob.size() * 16 <= 64u * 1024u;
+            if (std::getenv("SPT_NO_LDS_GEO")) sc->lds_geo = false;   // tests: drive small scenes through the large-scene path
+            if (!sc->lds_geo) assemble(true);
             if (blob.size() > 0x7fffffffull / 16) fail(SPT_ERR_UNSUPPORTED, "scene geometry larger than 32 GiB");
             sc->geo.upload(blob.data(), blob.size());
             d.geo = sc->geo.as<float4>();
             d.geo_f4 = (uint32_t)blob.size();
-            const size_t stack_bytes = (size_t)kLdsStack * 2 * kBlock * sizeof(uint32_t);   // (ref, t0) per LDS level
-            const size_t geo_bytes = blob.size() * 16;
-            sc->lds_geo = geo_bytes <= 32u * 1024u && stack_bytes + geo_bytes <= 64u * 1024u;
-            if (sc->lds_geo) d.lds_f4 = d.geo_f4;
-            else d.lds_f4 = 0;   // large scene: global fetches only (see trace.h)
-            (void)prefix_bytes; (void)staged_nodes; (void)kPrefixBudget;
+            d.lds_f4 = sc->lds_geo ? d.geo_f4 : 0u;   // large scene: global fetches only (see trace.h)
             sc->lds_bytes = stack_bytes + (size_t)d.lds_f4 * 16;
         }
         bool simple = s.env.width == 0 && s.n_lights > 0;

@@ -221,10 +221,55 @@ struct TStack {
     }
 };
 
+// ---- compressed 4-wide nodes (BLAS of large scenes) -------------------------------------------
+// For scenes that do not fit LDS the BLAS is collapsed to a 4-ary tree whose 64-byte node holds FOUR
+// child boxes quantised to 8 bits per coordinate relative to the node's own box:
+//     f4[0] = (p.xyz = node box min,  ex | ey << 8 | ez << 16 : biased power-of-two scale exponents)
+//     f4[1] = qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]   (one byte per child)
+//     f4[2] = qhi.y[4] qhi.z[4] ref0 ref1            f4[3] = ref2 ref3 - -
+// child box = p + 2^e * q, rounded OUTWARD on the host with the same f32 arithmetic, so it always
+// contains the exact child box: the slab test only culls, a looser box can never lose a hit.
+// Versus the 2-wide nodes: half the tree depth (half the dependent fetches) and 64 B per 4 children
+// instead of 128 B - the large scene is bound by random node fetches from L2 / Infinity Cache.
+struct Node4 {
+    float t0[4];
+    uint32_t ref[4];
+};
+template <bool kLds>
+SPT_DEV void node4_test(const DScene& sc, uint32_t off, f3 o, f3 inv_d, float t_min, Node4* out) {
+    const float4 n0 = geo_ld<kLds>(sc, off), n1 = geo_ld<kLds>(sc, off + 1u), n2 = geo_ld<kLds>(sc, off + 2u), n3 = geo_ld<kLds>(sc, off + 3u);
+    const uint32_t meta = __float_as_uint(n0.w);
+    const float sx = spt_u2f((meta & 0xffu) << 23), sy = spt_u2f(((meta >> 8) & 0xffu) << 23), sz = spt_u2f(((meta >> 16) & 0xffu) << 23);
+    const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z), qhx = __float_as_uint(n1.w);
+    const uint32_t qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
+    out->ref[0] = __float_as_uint(n2.z); out->ref[1] = __float_as_uint(n2.w);
+    out->ref[2] = __float_as_uint(n3.x); out->ref[3] = __float_as_uint(n3.y);
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; ++c) {
+        const uint32_t sh = 8u * c;
+        const float lx = n0.x + sx * (float)((qlx >> sh) & 0xffu), hx = n0.x + sx * (float)((qhx >> sh) & 0xffu);
+        const float ly = n0.y + sy * (float)((qly >> sh) & 0xffu), hy = n0.y + sy * (float)((qhy >> sh) & 0xffu);
+        const float lz = n0.z + sz * (float)((qlz >> sh) & 0xffu), hz = n0.z + sz * (float)((qhz >> sh) & 0xffu);
+        float t0;
+        const bool hit = slab_t0(make_float4(lx, ly, lz, 0.0f), make_float4(hx, hy, hz, 0.0f), o, inv_d, t_min, &t0);
+        out->t0[c] = hit ? t0 : spt_inf();   // absent children are stored as empty boxes (lo > hi)
+    }
+}
+// order the four (t0, ref) pairs by t0 (5 compare-exchanges)
+SPT_DEV void node4_sort(Node4* n) {
+#define SPT_CX(a, b)                                                          \
+    if (n->t0[a] > n->t0[b]) {                                                \
+        float tt = n->t0[a]; n->t0[a] = n->t0[b]; n->t0[b] = tt;              \
+        uint32_t rr = n->ref[a]; n->ref[a] = n->ref[b]; n->ref[b] = rr;       \
+    }
+    SPT_CX(0, 1) SPT_CX(2, 3) SPT_CX(0, 2) SPT_CX(1, 3) SPT_CX(1, 2)
+#undef SPT_CX
+}
+
 // Near-first walk of one wide-node tree.  `limit` is read on every test, so a closest-hit walk
 // (kClosest: cull with t0 <= limit, the tie rule) tightens as `leaf` lowers it; an any-hit walk culls
 // with t0 < limit.  leaf(first, count) returns true to stop the whole walk (any-hit found).
-template <bool kLds, bool kClosest, class LeafFn>
+template <bool kLds, bool kClosest, bool kN4, class LeafFn>
 SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o, f3 inv_d, float t_min, const float& limit,
                        TStack& st, LeafFn leaf) {
     const uint32_t base = st.sp;
@@ -232,6 +277,15 @@ SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o
     while (true) {
         if (cur & kLeaf) {
             if (leaf(leaf_first(cur), leaf_count(cur))) { st.sp = base; return true; }
+        } else if (kN4) {
+            Node4 n;
+            node4_test<kLds>(sc, nodes_off + 4u * cur, o, inv_d, t_min, &n);
+            node4_sort(&n);
+            // farthest first onto the stack, nearest becomes `cur`
+#pragma unroll
+            for (int c = 3; c >= 1; --c)
+                if ((kClosest ? n.t0[c] <= limit : n.t0[c] < limit) && n.t0[c] < spt_inf() && st.sp < kLdsStack + kSpillStack) st.push(n.ref[c], n.t0[c]);
+            if ((kClosest ? n.t0[0] <= limit : n.t0[0] < limit) && n.t0[0] < spt_inf()) { cur = n.ref[0]; continue; }
         } else {
             const uint32_t n = nodes_off + 4u * cur;
             float4 a = geo_ld<kLds>(sc, n), b = geo_ld<kLds>(sc, n + 1u), c = geo_ld<kLds>(sc, n + 2u), d = geo_ld<kLds>(sc, n + 3u);
@@ -293,7 +347,7 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
     const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(orr.d);
     if (!root_hit<true>(rlo, rhi, orr.o, inv_o, orr.t_min, h.t)) return;
-    walk_tree<kLds, true>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
+    walk_tree<kLds, true, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
             bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
@@ -317,7 +371,7 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
     const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(orr.d);
     if (!root_hit<false>(rlo, rhi, orr.o, inv_o, orr.t_min, t_max)) return false;
-    return walk_tree<kLds, false>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
+    return walk_tree<kLds, false, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
             if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w) && t > orr.t_min && t < t_max) return true;
@@ -344,7 +398,7 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
         const f3 inv_w = recip3(ray.d);
         const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
         if (root_hit<true>(tlo, thi, ray.o, inv_w, ray.t_min, h.t))
-        walk_tree<kLds, true>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
+        walk_tree<kLds, true, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
             for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds>(sc, i, ray, h, st);
             return false;
         });
@@ -367,7 +421,7 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
     const f3 inv_w = recip3(ray.d);
     const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
     if (!root_hit<false>(tlo, thi, ray.o, inv_w, ray.t_min, t_max)) return false;
-    return walk_tree<kLds, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
+    return walk_tree<kLds, false, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i)
             if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
         return false;
@@ -435,6 +489,17 @@ struct Walker {
         if (hr) { cur = rr; return true; }
         return false;
     }
+    // same for a compressed 4-wide BLAS node
+    SPT_DEV bool enter4(const DScene& sc) {
+        Node4 n;
+        node4_test<kLds>(sc, sc.o_blas + 4u * cur, oo, inv_o, t_min, &n);
+        node4_sort(&n);
+#pragma unroll
+        for (int c = 3; c >= 1; --c)
+            if (passes(n.t0[c]) && n.t0[c] < spt_inf() && st.sp < kLdsStack + kSpillStack) st.push(n.ref[c], n.t0[c]);
+        if (passes(n.t0[0]) && n.t0[0] < spt_inf()) { cur = n.ref[0]; return true; }
+        return false;
+    }
     SPT_DEV bool pop_to(uint32_t base) {
         while (st.sp > base) {
             uint32_t ref;
@@ -464,7 +529,7 @@ struct Walker {
                         return;
                     }
                 }
-            } else if (enter(sc, sc.o_blas, oo, inv_o)) {
+            } else if (kLds ? enter(sc, sc.o_blas, oo, inv_o) : enter4(sc)) {
                 return;
             }
             if (!pop_to(blas_base)) phase = 0u;
