@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 2
+#define SPT_ABI_VERSION 3
 
 typedef int32_t spt_status;
 enum {
@@ -135,16 +135,63 @@ typedef struct spt_material {
     float c2[3];     /* Diffuse substrate: bxdf_wo_fresnel (Diffuse::new, substrate.rs:127-137)     */
     uint32_t fresnel;    /* SPT_FRESNEL_*   (plastic lobes) */
     uint32_t substrate;  /* SPT_SUBSTRATE_* (plastic lobes) */
-    float pad;
+    uint32_t recipe;     /* 0: the constants above are the Bxdf; k > 0: material_recipes[k - 1] is
+                            evaluated at every hit (some parameter is an image texture) and the
+                            constants only hold the values at the textures' average colours */
 } spt_material;      /* 16 words = 64 B */
 
+/* ---- textures (the files of src/texture) -------------------------------------------------
+ * The closed `Texture` enum (src/texture/mod.rs:187-197) as a node table.  A named texture of
+ * the scene file is TexInputModifier(SrgbTex(base)) with the two wrappers present only when
+ * asked for (create_texture_from_params, mod.rs:210-243); binary ops point at named textures. */
+enum {
+    SPT_TEX_SCALAR = 0,    /* scalar.rs: value[3], alpha 1                              */
+    SPT_TEX_IMAGE = 1,     /* image_tex.rs: mip pyramid `image`, trilinear              */
+    SPT_TEX_ADD = 2, SPT_TEX_SUB = 3, SPT_TEX_MUL = 4, SPT_TEX_DIV = 5,   /* binary_op.rs: a (op) b */
+    SPT_TEX_SRGB = 6,      /* srgb_tex.rs: sRGB -> linear on r,g,b of child a            */
+    SPT_TEX_MODIFIER = 7   /* input_modifier.rs: input * tiling + offset, mode / wrap override, child a */
+};
+enum { SPT_TEXMODE_SPECIFIED = 0, SPT_TEXMODE_TEXCOORDS = 1, SPT_TEXMODE_POSITION = 2, SPT_TEXMODE_NORMAL = 3,
+       SPT_TEXMODE_TANGENT = 4, SPT_TEXMODE_BITANGENT = 5 };                /* mod.rs:20-28 */
+enum { SPT_TEXWRAP_REPEAT = 0, SPT_TEXWRAP_MIRROR_REPEAT = 1, SPT_TEXWRAP_CLAMP = 2, SPT_TEXWRAP_MIRROR_CLAMP = 3 };  /* mod.rs:36-42 */
+enum { SPT_CHAN_R = 0, SPT_CHAN_G = 1, SPT_CHAN_B = 2, SPT_CHAN_A = 3 };
+typedef struct spt_texture {
+    uint32_t type;        /* SPT_TEX_*                                              */
+    uint32_t a, b;        /* child texture indices (always smaller than this node's) */
+    uint32_t image;       /* IMAGE: index into images                                */
+    float value[3];       /* SCALAR                                                  */
+    int32_t mode, wrap;   /* MODIFIER: SPT_TEXMODE_* / SPT_TEXWRAP_*, -1 = keep the incoming one */
+    float tiling[3];      /* MODIFIER                                                */
+    float offset[3];
+    uint32_t pad;
+} spt_texture;            /* 16 words = 64 B */
+
+/* ImageTex::images (image_tex.rs:7-9): level 0 is the file as RGBA8 (what DynamicImage::get_pixel
+ * returns), the rest is generate_mipmap's box pyramid down to 1x1.  Texels are r | g<<8 | b<<16 | a<<24. */
+typedef struct spt_image { uint32_t first_level, n_levels; } spt_image;
+typedef struct spt_image_level { uint32_t width, height, first_texel, pad; } spt_image_level;
+
+/* A material whose parameters are not all constant: MaterialT::bxdf_context
+ * (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs) restated as data. */
+enum { SPT_MAT_LAMBERT = 0, SPT_MAT_CONDUCTOR = 1, SPT_MAT_DIELECTRIC = 2, SPT_MAT_PLASTIC = 3,
+       SPT_MAT_PBR_METALLIC = 4, SPT_MAT_PBR_SPECULAR = 5 };
+typedef struct spt_material_recipe {
+    uint32_t type;         /* SPT_MAT_* */
+    uint32_t tex[4];       /* texture indices: [0] albedo | ior | base_color | diffuse, [1] ior_k | metallic | specular,
+                              [2] roughness_x, [3] roughness_y (unused slots: 0) */
+    uint32_t rough_chan;   /* SPT_CHAN_* read from tex[2], tex[3] (the JSON loader always says R) */
+    uint32_t metal_chan;   /* SPT_CHAN_* read from tex[1] of PBR_METALLIC                      */
+    float ior;             /* DIELECTRIC / PLASTIC: int_ior / ext_ior                          */
+} spt_material_recipe;     /* 8 words */
+
 enum { SPT_SURF_DOUBLE_SIDED = 1u };
-typedef struct spt_surface {  /* src/core/surface.rs:14-22 (no maps: scalar-texture scope) */
+typedef struct spt_surface {  /* src/core/surface.rs:14-22 */
     uint32_t material;
     uint32_t flags;
     int32_t inside_medium;    /* medium index or -1 */
     float emissive[3];
-    float pad[2];
+    uint32_t normal_map;      /* texture index + 1, 0 = none (Surface::coord, surface.rs:65-78)      */
+    uint32_t emissive_map;    /* texture index + 1, 0 = none (Surface::emissive, surface.rs:49-55)   */
 } spt_surface;                /* 8 words */
 
 typedef struct spt_medium {   /* src/medium/homogeneous.rs:11-15 */
@@ -210,6 +257,12 @@ typedef struct spt_scene_desc {
     int32_t env_light_index;       /* index of the ENV light in lights, -1 if none */
     spt_alias_table light_alias;   /* POWER_IS only (n = n_lights) */
     spt_env env;
+    /* image textures (all zero / null for a scene with constant materials) */
+    uint32_t n_textures;          const spt_texture* textures;
+    uint32_t n_images;            const spt_image* images;
+    uint32_t n_image_levels;      const spt_image_level* image_levels;
+    uint32_t n_texels;            const uint32_t* texels;
+    uint32_t n_material_recipes;  const spt_material_recipe* material_recipes;
 } spt_scene_desc;
 
 /* PerspectiveCamera after ::new (src/camera/perspective.rs:15-27). */

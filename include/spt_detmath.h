@@ -71,13 +71,14 @@ SPT_HD int32_t spt_f2i_sat(float f) {
     return (int32_t)f;
 }
 
-/* floor for |x| < 2^31 */
+/* floor; values of magnitude >= 2^23 are integral already, inf and NaN pass through (as f32::floor) */
 SPT_HD float spt_floor(float x) {
+    if (!(spt_abs(x) < 8388608.0f)) return x;
     float t = (float)(int32_t)x;
     return (t > x) ? t - 1.0f : t;
 }
 
-/* Rust f32::round: half away from zero (|x| < 2^23 in our uses). */
+/* Rust f32::round: half away from zero; NaN stays NaN. */
 SPT_HD float spt_round(float x) {
     float a = spt_abs(x);
     float f = spt_floor(a);
@@ -181,6 +182,22 @@ SPT_HD float spt_exp(float x) {
     y = y * spt_u2f((uint32_t)(n2 + 127) << 23);
     return y;
 }
+
+/* ---- pow / log2 / trunc (image textures: sRGB decode, mip level, wrap modes) ---
+ * pow(x, y) for x >= 0 as exp(y * ln x): within ~1e-6 relative of a correctly rounded powf
+ * for the exponents used here (2.4), and the same bits on host and device. */
+SPT_HD float spt_pow(float x, float y) {
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : spt_inf());
+    return spt_exp(y * spt_log(x));
+}
+SPT_HD float spt_log2(float x) { return spt_log(x) * 1.44269504088896341f; }
+SPT_HD float spt_trunc(float x) {
+    if (!(spt_abs(x) < 8388608.0f)) return x; /* already integral, inf or NaN */
+    float t = (float)(int32_t)x;
+    return (t == 0.0f) ? spt_u2f(spt_f2u(x) & 0x80000000u) : t; /* keep the sign of zero like Rust's trunc */
+}
+/* f32::fract = x - trunc(x) */
+SPT_HD float spt_fract(float x) { return x - spt_trunc(x); }
 
 /* ---- atan / atan2 / asin / acos --------------------------------------------- */
 SPT_HD float spt_atan_pos(float x) { /* x >= 0 */

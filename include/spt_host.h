@@ -52,6 +52,9 @@ spt_status spt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t wi
  * `environment {type: "exr"}` (get_exr_image, src/core/loader.rs:374-390). */
 spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height, float** rgb_out);
 spt_status spt_host_write_exr(const char* path, const float* rgb, uint32_t width, uint32_t height);
+/* PNG -> RGBA8 texels (r | g<<8 | b<<16 | a<<24) the way `image::open` + `get_pixel` present an
+ * `image_file` texture (get_image, src/core/loader.rs:366-371); free with spt_host_free. */
+spt_status spt_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out);
 void spt_host_free(void* p);
 
 const char* spt_host_last_error(void);

@@ -104,6 +104,8 @@ struct Math {  // D2: deterministic kernels by default, libm on request
     float exp(float x) const { return libm ? std::exp(x) : spt_exp(x); }
     float acos(float x) const { return libm ? std::acos(x) : spt_acos(x); }
     float atan2(float y, float x) const { return libm ? std::atan2(y, x) : spt_atan2(y, x); }
+    float powf(float x, float y) const { return libm ? std::pow(x, y) : spt_pow(x, y); }
+    float log2(float x) const { return libm ? std::log2(x) : spt_log2(x); }
     Color exp(Color c) const { return col(exp(c.r), exp(c.g), exp(c.b)); }
 };
 
@@ -118,9 +120,16 @@ struct Rng {
 struct Ray {
     Vec3 origin, direction;
     float t_min;
+    // AuxiliaryRay (ray.rs:9-15): only camera rays carry one (generate_ray_with_aux_ray, camera/mod.rs:15-21)
+    bool has_aux = false;
+    Vec3 x_origin{0, 0, 0}, x_direction{0, 0, 0}, y_origin{0, 0, 0}, y_direction{0, 0, 0};
 };
 constexpr float T_MIN_EPS = 0.0001f;
-inline Ray make_ray(Vec3 o, Vec3 d) { return Ray{o, d, T_MIN_EPS}; }
+inline Ray make_ray(Vec3 o, Vec3 d) {
+    Ray r;
+    r.origin = o; r.direction = d; r.t_min = T_MIN_EPS;
+    return r;
+}
 inline Vec3 point_at(const Ray& r, float t) { return r.origin + r.direction * t; }
 
 // glam Affine3A stored as 3 columns + translation (spt_instance::inv / fwd)
@@ -138,6 +147,7 @@ struct Inter {
     int32_t prim = -1;       // BasicPrimitiveRef: triangle (absolute) or sphere index
     int32_t prim_type = -1;  // SPT_PRIM_*
     float bv = 0, bw = 0;    // barycentrics of the accepted triangle hit
+    float texcoords[2] = {0, 0}, duvdx[2] = {0, 0}, duvdy[2] = {0, 0};
     int32_t cand_instance = -1;  // instance being traversed (for the ORACLE_TIE_MIN_ID rule)
 };
 
@@ -223,6 +233,8 @@ inline bool triangle_intersect(const Ctx& cx, uint32_t tri, const Ray& ray, Inte
             inter.normal = normalize((v3(a.n[0]) * u + v3(a.n[1]) * v) + v3(a.n[2]) * w);
             inter.tangent = (v3(a.t[0]) * u + v3(a.t[1]) * v) + v3(a.t[2]) * w;
             inter.bitangent = (v3(a.b[0]) * u + v3(a.b[1]) * v) + v3(a.b[2]) * w;
+            inter.texcoords[0] = (a.uv[0][0] * u + a.uv[1][0] * v) + a.uv[2][0] * w;   // lerp_point2, triangle.rs:291-302
+            inter.texcoords[1] = (a.uv[0][1] * u + a.uv[1][1] * v) + a.uv[2][1] * w;
             inter.prim = (int32_t)tri;
             inter.instance = inter.cand_instance;
             inter.prim_type = SPT_PRIM_MESH;
@@ -271,7 +283,14 @@ inline void sphere_frame(Vec3 norm, Vec3* tangent, Vec3* bitangent) {
         *tangent = v3(0, 0, -1);
     }
 }
-// sphere.rs:59-84 (texcoords only feed image textures: not computed)
+// sphere.rs:138-145
+inline void sphere_normal_to_texcoords(const Ctx& cx, Vec3 p, float* uv) {
+    float theta = cx.m.acos(p.y);
+    float phi = cx.m.atan2(p.x, p.z) + SPT_PI;
+    uv[0] = phi * 0.5f * SPT_FRAC_1_PI;
+    uv[1] = theta * SPT_FRAC_1_PI;
+}
+// sphere.rs:59-84
 inline bool sphere_intersect(const Ctx& cx, uint32_t si, const Ray& ray, Inter& inter) {
     const spt_sphere& s = cx.d->spheres[si];
     float mn, mx;
@@ -283,6 +302,7 @@ inline bool sphere_intersect(const Ctx& cx, uint32_t si, const Ray& ray, Inter& 
             Vec3 norm = (point_at(ray, t) - v3(s.center)) / s.radius;
             inter.normal = norm;
             sphere_frame(norm, &inter.tangent, &inter.bitangent);
+            sphere_normal_to_texcoords(cx, norm, inter.texcoords);
             inter.prim = (int32_t)si;
             inter.prim_type = SPT_PRIM_SPHERE;
             inter.bv = 0.0f;
@@ -350,7 +370,10 @@ inline bool blas_intersect_test(const Ctx& cx, const spt_mesh& mesh, const Ray& 
 
 // ---------------------------------------------------------------- src/primitive/instance.rs:88-109
 inline Ray transformed_by(const Ray& r, const float* m) {  // src/core/ray.rs:33-41: direction NOT renormalised
-    return Ray{xf_point(m, r.origin), xf_vector(m, r.direction), r.t_min};
+    Ray t = r;   // `..self`: the auxiliary ray stays in world space (never read in object space)
+    t.origin = xf_point(m, r.origin);
+    t.direction = xf_vector(m, r.direction);
+    return t;
 }
 inline bool instance_intersect(const Ctx& cx, uint32_t ii, const Ray& ray, Inter& inter) {
     cx.c->insts++;
@@ -447,9 +470,261 @@ inline Coordinate coord_from_tangent_normal(Vec3 t, Vec3 n, Vec3 hemisphere) {
     return c;
 }
 
-// src/core/surface.rs:65-95 (no normal map in scope)
-inline Coordinate surface_coord(const spt_surface& s, const Ray& ray, const Inter& inter) {
+
+// ---------------------------------------------------------------- src/core/intersection.rs:28-84
+inline bool solve_linear_system_2x2(const float a[2][2] /* columns */, const float b[2], float* x1, float* x2) {  // intersection.rs:104-118
+    float det = a[0][0] * a[1][1] - a[0][1] * a[1][0];   // Mat2::determinant
+    if (det != 0.0f) {
+        float temp = b[1] * a[0][0] - b[0] * a[0][1];
+        *x2 = temp / det;
+        *x1 = (spt_abs(a[0][0]) > spt_abs(a[0][1])) ? (b[0] - a[1][0] * *x2) / a[0][0] : (b[1] - a[1][1] * *x2) / a[0][1];
+        return true;
+    }
+    return false;
+}
+inline void calc_differential(Inter& it, const Ray& ray) {
+    if (!ray.has_aux) return;
+    Vec3 p = point_at(ray, it.t);
+    float d = dot(p, it.normal);
+    float tx = (d - dot(ray.x_origin, it.normal)) / dot(ray.x_direction, it.normal);
+    Vec3 px = ray.x_origin + ray.x_direction * tx;
+    float ty = (d - dot(ray.y_origin, it.normal)) / dot(ray.y_direction, it.normal);
+    Vec3 py = ray.y_origin + ray.y_direction * ty;
+    Vec3 dpdx = px - p, dpdy = py - p;
+    float bx[2], by[2], a[2][2];
+    float ax = spt_abs(it.normal.x), ay = spt_abs(it.normal.y), az = spt_abs(it.normal.z);
+    if (ax >= ay && ax >= az) {
+        bx[0] = dpdx.y; bx[1] = dpdx.z; by[0] = dpdy.y; by[1] = dpdy.z;
+        a[0][0] = it.tangent.y; a[0][1] = it.tangent.z; a[1][0] = it.bitangent.y; a[1][1] = it.bitangent.z;
+    } else if (ay >= az) {
+        bx[0] = dpdx.z; bx[1] = dpdx.x; by[0] = dpdy.z; by[1] = dpdy.x;
+        a[0][0] = it.tangent.z; a[0][1] = it.tangent.x; a[1][0] = it.bitangent.z; a[1][1] = it.bitangent.x;
+    } else {
+        bx[0] = dpdx.x; bx[1] = dpdx.y; by[0] = dpdy.x; by[1] = dpdy.y;
+        a[0][0] = it.tangent.x; a[0][1] = it.tangent.y; a[1][0] = it.bitangent.x; a[1][1] = it.bitangent.y;
+    }
+    float x1, x2;
+    if (solve_linear_system_2x2(a, bx, &x1, &x2)) { it.duvdx[0] = x1; it.duvdx[1] = x2; }
+    if (solve_linear_system_2x2(a, by, &x1, &x2)) { it.duvdy[0] = x1; it.duvdy[1] = x2; }
+}
+
+// ---------------------------------------------------------------- src/texture/*.rs
+struct Vec4 {
+    float x, y, z, w;
+};
+inline Vec4 operator+(Vec4 a, Vec4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline Vec4 operator-(Vec4 a, Vec4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline Vec4 operator*(Vec4 a, Vec4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+inline Vec4 operator/(Vec4 a, Vec4 b) { return {a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w}; }
+inline Vec4 operator*(Vec4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+
+// TextureInput (mod.rs:50-62); `specified` is never selectable from a scene file
+struct TexInput {
+    Vec3 position, normal, tangent, bitangent;
+    float texcoords[2], duvdx[2], duvdy[2];
+    int32_t mode = SPT_TEXMODE_TEXCOORDS, wrap = SPT_TEXWRAP_REPEAT;
+};
+inline TexInput tex_input(const Inter& it) {  // From<&Intersection> (mod.rs:143-157)
+    TexInput in;
+    in.position = it.position; in.normal = it.normal; in.tangent = it.tangent; in.bitangent = it.bitangent;
+    for (int k = 0; k < 2; ++k) { in.texcoords[k] = it.texcoords[k]; in.duvdx[k] = it.duvdx[k]; in.duvdy[k] = it.duvdy[k]; }
+    return in;
+}
+inline void tex_value_vec2_wrapped(const TexInput& in, float* u, float* v) {  // mod.rs:73-141
+    float val[2];
+    switch (in.mode) {
+    case SPT_TEXMODE_TEXCOORDS: val[0] = in.texcoords[0]; val[1] = in.texcoords[1]; break;
+    case SPT_TEXMODE_POSITION: val[0] = in.position.x; val[1] = in.position.y; break;
+    case SPT_TEXMODE_NORMAL: val[0] = in.normal.x; val[1] = in.normal.y; break;
+    case SPT_TEXMODE_TANGENT: val[0] = in.tangent.x; val[1] = in.tangent.y; break;
+    case SPT_TEXMODE_BITANGENT: val[0] = in.bitangent.x; val[1] = in.bitangent.y; break;
+    default: val[0] = 0.0f; val[1] = 0.0f; break;
+    }
+    float out[2];
+    for (int k = 0; k < 2; ++k) {
+        float x = val[k];
+        switch (in.wrap) {
+        case SPT_TEXWRAP_REPEAT: {
+            float fr = spt_fract(x);
+            out[k] = (x >= 0.0f) ? fr : 1.0f + fr;
+            break;
+        }
+        case SPT_TEXWRAP_MIRROR_REPEAT: {
+            float fr = spt_fract(x);
+            float xn = (x >= 0.0f) ? fr : 1.0f + fr;
+            out[k] = (spt_f2i_sat(x) % 2 == 0) ? xn : 1.0f - xn;
+            break;
+        }
+        case SPT_TEXWRAP_CLAMP: out[k] = spt_clamp(x, 0.0f, 1.0f); break;
+        default: out[k] = spt_abs(spt_clamp(x, 0.0f, 1.0f)); break;
+        }
+    }
+    *u = out[0];
+    *v = out[1];
+}
+inline Vec4 rgba_to_vec4(uint32_t px) {  // image_tex.rs:153-160
+    return {(float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f, (float)(px >> 24) / 255.0f};
+}
+inline Vec4 sample_bilinear(const Ctx& cx, const spt_image_level& L, float u, float v) {  // image_tex.rs:102-125
+    const uint32_t* tx = cx.d->texels + L.first_texel;
+    float x = u * (float)L.width;
+    int32_t x1 = spt_f2i_sat(spt_round(x));
+    int32_t x0 = (int32_t)((uint32_t)x1 - 1u);   // wrapping, as release-mode Rust
+    float xt = x - (float)x0 - 0.5f;
+    int32_t wmax = (int32_t)L.width - 1, hmax = (int32_t)L.height - 1;
+    x0 = x0 < 0 ? 0 : (x0 > wmax ? wmax : x0);
+    x1 = x1 < 0 ? 0 : (x1 > wmax ? wmax : x1);
+    float y = v * (float)L.height;
+    int32_t y1 = spt_f2i_sat(spt_round(y));
+    int32_t y0 = (int32_t)((uint32_t)y1 - 1u);
+    float yt = y - (float)y0 - 0.5f;
+    y0 = y0 < 0 ? 0 : (y0 > hmax ? hmax : y0);
+    y1 = y1 < 0 ? 0 : (y1 > hmax ? hmax : y1);
+    Vec4 c00 = rgba_to_vec4(tx[(size_t)y0 * L.width + x0]), c01 = rgba_to_vec4(tx[(size_t)y1 * L.width + x0]);
+    Vec4 c10 = rgba_to_vec4(tx[(size_t)y0 * L.width + x1]), c11 = rgba_to_vec4(tx[(size_t)y1 * L.width + x1]);
+    Vec4 c0 = c00 * (1.0f - yt) + c01 * yt;
+    Vec4 c1 = c10 * (1.0f - yt) + c11 * yt;
+    return c0 * (1.0f - xt) + c1 * xt;
+}
+inline Vec4 sample_trilinear(const Ctx& cx, const spt_image& im, float u, float v, const float* duvdx, const float* duvdy) {  // image_tex.rs:127-151
+    if (im.n_levels == 0) return {0, 0, 0, 0};
+    const spt_image_level* lv = cx.d->image_levels + im.first_level;
+    float sx = (float)lv[0].width, sy = (float)lv[0].height;
+    float dxx = duvdx[0] * sx, dxy = duvdx[1] * sy, dyx = duvdy[0] * sx, dyy = duvdy[1] * sy;
+    float lx = spt_sqrt(dxx * dxx + dxy * dxy), ly = spt_sqrt(dyx * dyx + dyy * dyy);
+    float level = spt_clamp(cx.m.log2(spt_max(lx, ly) + 0.001f), 0.0f, (float)(im.n_levels - 1));
+    uint32_t l0 = spt_f2u_sat(spt_floor(level));
+    if (l0 + 1 == im.n_levels) return sample_bilinear(cx, lv[l0], u, v);
+    float lt = level - (float)l0;
+    Vec4 c0 = sample_bilinear(cx, lv[l0], u, v), c1 = sample_bilinear(cx, lv[l0 + 1], u, v);
+    return c0 * (1.0f - lt) + c1 * lt;
+}
+inline float srgb_to_linear(const Ctx& cx, float sv) {  // srgb_tex.rs:53-59
+    return (sv <= 0.04045f) ? sv / 12.92f : cx.m.powf((sv + 0.055f) / 1.055f, 2.4f);
+}
+// (color_at, float_at) of the closed Texture enum as one RGBA evaluation: every variant acts per channel,
+// ScalarTex reports alpha 1 (scalar.rs:29-34) and SrgbTex leaves alpha alone (srgb_tex.rs:22-28)
+Vec4 tex_eval(const Ctx& cx, uint32_t node, TexInput in) {
+    const spt_texture& t = cx.d->textures[node];
+    switch (t.type) {
+    case SPT_TEX_SCALAR: return {t.value[0], t.value[1], t.value[2], 1.0f};
+    case SPT_TEX_IMAGE: {
+        float u, v;
+        tex_value_vec2_wrapped(in, &u, &v);
+        return sample_trilinear(cx, cx.d->images[t.image], u, v, in.duvdx, in.duvdy);
+    }
+    case SPT_TEX_ADD: return tex_eval(cx, t.a, in) + tex_eval(cx, t.b, in);
+    case SPT_TEX_SUB: return tex_eval(cx, t.a, in) - tex_eval(cx, t.b, in);
+    case SPT_TEX_MUL: return tex_eval(cx, t.a, in) * tex_eval(cx, t.b, in);
+    case SPT_TEX_DIV: return tex_eval(cx, t.a, in) / tex_eval(cx, t.b, in);
+    case SPT_TEX_SRGB: {
+        Vec4 c = tex_eval(cx, t.a, in);
+        return {srgb_to_linear(cx, c.x), srgb_to_linear(cx, c.y), srgb_to_linear(cx, c.z), c.w};
+    }
+    default: {  // TexInputModifier::apply_modifier (input_modifier.rs:35-50)
+        Vec3 tl = v3(t.tiling), of = v3(t.offset);
+        auto app = [&](Vec3 a) { return v3(a.x * tl.x + of.x, a.y * tl.y + of.y, a.z * tl.z + of.z); };
+        TexInput m = in;
+        m.position = app(in.position); m.normal = app(in.normal); m.tangent = app(in.tangent); m.bitangent = app(in.bitangent);
+        m.texcoords[0] = in.texcoords[0] * tl.x + of.x; m.texcoords[1] = in.texcoords[1] * tl.y + of.y;
+        m.duvdx[0] = in.duvdx[0] * tl.x; m.duvdx[1] = in.duvdx[1] * tl.y;
+        m.duvdy[0] = in.duvdy[0] * tl.x; m.duvdy[1] = in.duvdy[1] * tl.y;
+        if (t.mode >= 0) m.mode = t.mode;
+        if (t.wrap >= 0) m.wrap = t.wrap;
+        return tex_eval(cx, t.a, m);
+    }
+    }
+}
+inline Color tex_color(const Ctx& cx, uint32_t node, const TexInput& in) { Vec4 c = tex_eval(cx, node, in); return col(c.x, c.y, c.z); }
+inline float tex_float(const Ctx& cx, uint32_t node, const TexInput& in, uint32_t chan) {
+    Vec4 c = tex_eval(cx, node, in);
+    return chan == SPT_CHAN_R ? c.x : (chan == SPT_CHAN_G ? c.y : (chan == SPT_CHAN_B ? c.z : c.w));
+}
+
+inline float fresnel_moment1(float eta) {  // src/bxdf/util.rs:123-134
+    float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
+    if (eta < 1.0f) return 0.45966f - 1.73965f * eta + 3.37668f * eta2 - 3.904945f * eta3 + 2.49277f * eta4 - 0.68441f * eta5;
+    return -4.61686f + 11.1136f * eta - 10.4646f * eta2 + 5.11455f * eta3 - 1.27198f * eta4 + 0.12746f * eta5;
+}
+// MaterialT::bxdf_context (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs)
+// for a material with image-backed parameters; constant materials were evaluated by the loader.
+inline spt_material material_at(const Ctx& cx, const spt_material& constant, const Inter& inter) {
+    if (constant.recipe == 0) return constant;
+    const spt_material_recipe& r = cx.d->material_recipes[constant.recipe - 1];
+    TexInput in = tex_input(inter);
+    spt_material m;
+    std::memset(&m, 0, sizeof m);
+    m.recipe = constant.recipe;
+    auto store = [](float* dst, Color c) { dst[0] = c.r; dst[1] = c.g; dst[2] = c.b; };
+    auto roughness = [&](bool squared) {
+        float rx = tex_float(cx, r.tex[2], in, r.rough_chan), ry = tex_float(cx, r.tex[3], in, r.rough_chan);
+        m.ax = squared ? rx * rx : rx;
+        m.ay = squared ? ry * ry : ry;
+        return m.ax < 0.0001f || m.ay < 0.0001f;
+    };
+    switch (r.type) {
+    case SPT_MAT_LAMBERT:
+        m.bxdf = SPT_BXDF_LAMBERT;
+        store(m.c0, tex_color(cx, r.tex[0], in));
+        break;
+    case SPT_MAT_CONDUCTOR:
+        store(m.c0, tex_color(cx, r.tex[0], in));
+        store(m.c1, tex_color(cx, r.tex[1], in));
+        m.bxdf = roughness(true) ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
+        break;
+    case SPT_MAT_DIELECTRIC:
+        m.ior = r.ior;
+        m.bxdf = roughness(true) ? SPT_BXDF_SPECULAR_DIELECTRIC : SPT_BXDF_MICROFACET_DIELECTRIC;
+        break;
+    case SPT_MAT_PLASTIC: {  // plastic.rs:60-85: roughness NOT squared; Diffuse::new (substrate.rs:127-137)
+        Color albedo = tex_color(cx, r.tex[0], in);
+        m.ior = r.ior;
+        m.bxdf = roughness(false) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        m.fresnel = SPT_FRESNEL_DIELECTRIC;
+        m.substrate = SPT_SUBSTRATE_DIFFUSE;
+        store(m.c0, albedo);
+        float fdr = 2.0f * fresnel_moment1(1.0f / r.ior);
+        store(m.c2, (albedo * SPT_FRAC_1_PI) / (((gray(1.0f) - albedo * fdr) * r.ior) * r.ior));
+        break;
+    }
+    case SPT_MAT_PBR_METALLIC: {  // pbr_metallic.rs:75-104
+        Color base = tex_color(cx, r.tex[0], in);
+        bool spec = roughness(true);
+        float metallic = tex_float(cx, r.tex[1], in, r.metal_chan);
+        store(m.c1, metallic * base + (1.0f - metallic) * gray(0.04f));
+        store(m.c0, base * (1.0f - metallic));
+        m.bxdf = spec ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        m.fresnel = SPT_FRESNEL_SCHLICK;
+        m.substrate = SPT_SUBSTRATE_LAMBERT;
+        break;
+    }
+    default: {  // pbr_specular.rs:60-92
+        store(m.c0, tex_color(cx, r.tex[0], in));
+        store(m.c1, tex_color(cx, r.tex[1], in));
+        m.bxdf = roughness(true) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        m.fresnel = SPT_FRESNEL_SCHLICK;
+        m.substrate = SPT_SUBSTRATE_LAMBERT;
+        break;
+    }
+    }
+    return m;
+}
+// Surface::emissive (surface.rs:49-55)
+inline Color surface_emissive(const Ctx& cx, const spt_surface& s, const Inter& inter) {
+    Color e = col(s.emissive);
+    if (s.emissive_map) e = e * tex_color(cx, s.emissive_map - 1, tex_input(inter));
+    return e;
+}
+
+// src/core/surface.rs:65-95
+inline Coordinate surface_coord(const Ctx& cx, const spt_surface& s, const Ray& ray, const Inter& inter) {
     Vec3 shade_normal = inter.normal;
+    if (s.normal_map) {
+        Color value = tex_color(cx, s.normal_map - 1, tex_input(inter));
+        Color nc = value * 2.0f - gray(1.0f);
+        Vec3 local = normalize(v3(nc.r, nc.g, nc.b));
+        shade_normal = normalize((local.x * normalize(inter.tangent) + local.y * normalize(inter.bitangent)) + local.z * inter.normal);
+    }
     bool hit_back = dot(ray.direction, inter.normal) > 0.0f;
     bool ds = (s.flags & SPT_SURF_DOUBLE_SIDED) != 0;
     return coord_from_tangent_normal(inter.tangent, (ds && hit_back) ? -shade_normal : shade_normal,
@@ -918,13 +1193,13 @@ inline void env_lookup(const spt_env& e, float theta, float phi, Color* c_out, f
     int32_t W = (int32_t)e.width, H = (int32_t)e.height;
     float x = phi * 0.5f * SPT_FRAC_1_PI * (float)e.width;
     int32_t x1 = spt_f2i_sat(spt_round(x));
-    int32_t x0 = x1 - 1;
+    int32_t x0 = (int32_t)((uint32_t)x1 - 1u);   // wrapping, as release-mode Rust
     float xt = x - (float)x0 - 0.5f;
     uint32_t ux0 = (uint32_t)(x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0));
     uint32_t ux1 = (uint32_t)(x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1));
     float y = theta * SPT_FRAC_1_PI * (float)e.height;
     int32_t y1 = spt_f2i_sat(spt_round(y));
-    int32_t y0 = y1 - 1;
+    int32_t y0 = (int32_t)((uint32_t)y1 - 1u);
     float yt = y - (float)y0 - 0.5f;
     uint32_t uy0 = (uint32_t)(y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0));
     uint32_t uy1 = (uint32_t)(y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1));
@@ -951,6 +1226,7 @@ inline void env_strength_pdf(const Ctx& cx, Vec3 wi, Color* c, float* pdf) {
 // Instance::sample (src/primitive/instance.rs:111-129) over Sphere::sample / BvhAccel<Triangle>::sample
 struct ShapeSample {
     Vec3 position, normal, tangent, bitangent;
+    float texcoords[2];
     float pdf;
 };
 inline ShapeSample instance_sample(const Ctx& cx, const spt_instance& in, Rng& rng) {
@@ -968,6 +1244,7 @@ inline ShapeSample instance_sample(const Ctx& cx, const spt_instance& in, Rng& r
         Vec3 norm = v3(sin_theta * cphi, sin_theta * sphi, cos_theta);
         s.position = v3(sp.center) + norm * sp.radius;
         s.normal = norm;
+        sphere_normal_to_texcoords(cx, norm, s.texcoords);
         sphere_frame(norm, &s.tangent, &s.bitangent);
         pdf = 0.25f * SPT_FRAC_1_PI;
     } else {  // bvh.rs:293-298 + triangle.rs:224-271
@@ -990,6 +1267,8 @@ inline ShapeSample instance_sample(const Ctx& cx, const spt_instance& in, Rng& r
         s.normal = (v3(a.n[0]) * u + v3(a.n[1]) * v) + v3(a.n[2]) * w;
         s.tangent = (v3(a.t[0]) * u + v3(a.t[1]) * v) + v3(a.t[2]) * w;
         s.bitangent = (v3(a.b[0]) * u + v3(a.b[1]) * v) + v3(a.b[2]) * w;
+        s.texcoords[0] = (a.uv[0][0] * u + a.uv[1][0] * v) + a.uv[2][0] * w;   // Vec2 * f32 sums (triangle.rs:258)
+        s.texcoords[1] = (a.uv[0][1] * u + a.uv[1][1] * v) + a.uv[2][1] * w;
         pdf = (1.0f / spt_max(area, 0.001f)) / (float)mesh.tri_count;
     }
     float original_area = length(cross(s.tangent, s.bitangent));
@@ -1046,7 +1325,10 @@ inline void light_sample(const Ctx& cx, const spt_light& l, Vec3 position, Rng& 
         const spt_instance& in = cx.d->instances[l.instance];
         const spt_surface& sf = cx.d->surfaces[in.surface];
         ShapeSample s = instance_sample(cx, in, rng);
-        Color emissive = col(sf.emissive);
+        Inter at;   // the sampled point as the Intersection Surface::emissive sees (no differentials)
+        at.position = s.position; at.normal = s.normal; at.tangent = s.tangent; at.bitangent = s.bitangent;
+        at.texcoords[0] = s.texcoords[0]; at.texcoords[1] = s.texcoords[1];
+        Color emissive = surface_emissive(cx, sf, at);
         Vec3 light_vec = s.position - position;
         float dist_sqr = length_squared(light_vec);
         float dist = spt_sqrt(dist_sqr);
@@ -1219,6 +1501,7 @@ Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
     while (curr_depth < max_depth) {
         Inter inter;
         bool does_hit = aggregate_intersect(cx, ray, inter);
+        if (does_hit) calc_differential(inter, ray);   // pt.rs:51-53
 
         if (curr_medium >= 0) {  // pt.rs:56-96
             const spt_medium& md = d.mediums[curr_medium];
@@ -1271,10 +1554,10 @@ Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
             Vec3 po = point_at(ray, inter.t);
             const spt_instance& in = d.instances[inter.instance];
             const spt_surface& surf = d.surfaces[in.surface];
-            const spt_material& mt = d.materials[surf.material];
-            Coordinate coord_po = surface_coord(surf, ray, inter);
+            const spt_material mt = material_at(cx, d.materials[surf.material], inter);   // Surface::scatter_and_coord
+            Coordinate coord_po = surface_coord(cx, surf, ray, inter);
 
-            Color li_emissive = col(surf.emissive);
+            Color li_emissive = surface_emissive(cx, surf, inter);
             if (luminance(li_emissive) > 0.0f) {
                 float weight = 1.0f;
                 if (curr_depth != 0) {
@@ -1383,6 +1666,8 @@ int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_r
     std::vector<Counters> counters((size_t)n_threads);
     const float aspect = (float)p.width / (float)p.height;
     const float width_inv = 1.0f / (float)p.width, height_inv = 1.0f / (float)p.height;
+    const float spp_sqrt_inv = 1.0f / spt_sqrt((float)p.spp);                               // pt.rs:253-254
+    const float aux_dx = aspect * width_inv * spp_sqrt_inv, aux_dy = height_inv * spp_sqrt_inv;
     auto work = [&](int t) {
         Ctx cx{desc, f, Math{f.libm}, &counters[(size_t)t]};
         uint32_t per = nrows / (uint32_t)n_threads;
@@ -1399,6 +1684,12 @@ int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_r
                     float x = (((float)i + ox) * width_inv - 0.5f) * aspect;             // pt.rs:269
                     float y = ((float)(p.height - j - 1) + oy) * height_inv - 0.5f;      // pt.rs:270-271
                     Ray ray = camera_ray(*cam, x, y);
+                    {   // generate_ray_with_aux_ray (camera/mod.rs:15-21) with the offsets of pt.rs:272-275
+                        Ray rx = camera_ray(*cam, x + aux_dx, y), ry = camera_ray(*cam, x, y + aux_dy);
+                        ray.has_aux = true;
+                        ray.x_origin = rx.origin; ray.x_direction = rx.direction;
+                        ray.y_origin = ry.origin; ray.y_direction = ry.direction;
+                    }
                     Color c = trace_ray(cx, ray, rng, p.max_depth);
                     sum = sum + c;  // film.rs:87: color += sample.color
                 }
@@ -1505,9 +1796,42 @@ void oracle_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, flo
         case 10: out[i] = a[i] / b[i]; break;
         case 11: out[i] = spt_max(a[i], b[i]); break;
         case 12: out[i] = spt_min(a[i], b[i]); break;
+        case 13: out[i] = spt_pow(a[i], b[i]); break;
+        case 14: out[i] = spt_log2(a[i]); break;
+        case 15: out[i] = spt_trunc(a[i]); break;
+        case 16: out[i] = spt_fract(a[i]); break;
         default: out[i] = 0.0f; break;
         }
     }
+}
+// texture graph at explicit inputs: `in` holds 18 floats per sample
+// (position, normal, tangent, bitangent, texcoords, duvdx, duvdy), out 4 (r, g, b, a)
+int oracle_tex_eval(const spt_scene_desc* desc, uint32_t flags, uint32_t node, uint32_t n, const float* in, float* rgba) {
+    if (!desc || node >= desc->n_textures) return 1;
+    Counters cn;
+    Ctx cx{desc, Flags{(flags & ORACLE_SLAB_RECIPROCAL) != 0, (flags & ORACLE_BRUTE_FORCE) != 0, (flags & ORACLE_LIBM) != 0, (flags & ORACLE_TIE_MIN_ID) != 0},
+           Math{(flags & ORACLE_LIBM) != 0}, &cn};
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* f = in + 18 * (size_t)i;
+        TexInput ti;
+        ti.position = v3(f); ti.normal = v3(f + 3); ti.tangent = v3(f + 6); ti.bitangent = v3(f + 9);
+        ti.texcoords[0] = f[12]; ti.texcoords[1] = f[13];
+        ti.duvdx[0] = f[14]; ti.duvdx[1] = f[15]; ti.duvdy[0] = f[16]; ti.duvdy[1] = f[17];
+        Vec4 c = tex_eval(cx, node, ti);
+        rgba[4 * i] = c.x; rgba[4 * i + 1] = c.y; rgba[4 * i + 2] = c.z; rgba[4 * i + 3] = c.w;
+    }
+    return 0;
+}
+// Intersection::calc_differential: ray (o, d, aux x_o, x_d, y_o, y_d = 18 floats), hit (t, normal, tangent, bitangent = 10 floats)
+void oracle_calc_differential(const float* ray18, const float* hit10, float duvdx[2], float duvdy[2]) {
+    Ray r = make_ray(v3(ray18), v3(ray18 + 3));
+    r.has_aux = true;
+    r.x_origin = v3(ray18 + 6); r.x_direction = v3(ray18 + 9); r.y_origin = v3(ray18 + 12); r.y_direction = v3(ray18 + 15);
+    Inter it;
+    it.t = hit10[0];
+    it.normal = v3(hit10 + 1); it.tangent = v3(hit10 + 4); it.bitangent = v3(hit10 + 7);
+    calc_differential(it, r);
+    duvdx[0] = it.duvdx[0]; duvdx[1] = it.duvdx[1]; duvdy[0] = it.duvdy[0]; duvdy[1] = it.duvdy[1];
 }
 void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out) {
     spt_rng r = spt_rng_seed(seed, pixel, sample);

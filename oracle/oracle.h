@@ -47,6 +47,11 @@ uint32_t oracle_alias_sample(const spt_alias_table* a, float rand, float* prob);
 void oracle_env_lookup(const spt_scene_desc* d, const float wi[3], float rgb[3], float* pdf);
 void oracle_camera_ray(const spt_camera* cam, float x, float y, float o[3], float dir[3]);
 void oracle_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out);
+/* image-texture seams (src/texture, src/core/intersection.rs:28-84): texture graph at explicit inputs
+ * (18 floats per sample: position, normal, tangent, bitangent, texcoords, duvdx, duvdy -> rgba), and
+ * calc_differential (ray + aux ray = 18 floats, hit t/normal/tangent/bitangent = 10 floats) */
+int oracle_tex_eval(const spt_scene_desc* desc, uint32_t flags, uint32_t node, uint32_t n, const float* in, float* rgba);
+void oracle_calc_differential(const float* ray18, const float* hit10, float duvdx[2], float duvdy[2]);
 void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 uint64_t oracle_rng_state(uint64_t seed, uint32_t pixel, uint32_t sample);
 void oracle_r2_offsets(uint32_t pixel, uint32_t spp, uint32_t n, float* out);

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 2
+SPT_ABI_VERSION = 3
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -74,12 +74,31 @@ class Instance(C.Structure):
 class Material(C.Structure):
     _fields_ = [("bxdf", C.c_uint32), ("c0", C.c_float * 3), ("c1", C.c_float * 3), ("ax", C.c_float),
                 ("ay", C.c_float), ("ior", C.c_float), ("c2", C.c_float * 3), ("fresnel", C.c_uint32),
-                ("substrate", C.c_uint32), ("pad", C.c_float)]
+                ("substrate", C.c_uint32), ("recipe", C.c_uint32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("image", C.c_uint32),
+                ("value", C.c_float * 3), ("mode", C.c_int32), ("wrap", C.c_int32), ("tiling", C.c_float * 3),
+                ("offset", C.c_float * 3), ("pad", C.c_uint32)]
+
+
+class Image(C.Structure):
+    _fields_ = [("first_level", C.c_uint32), ("n_levels", C.c_uint32)]
+
+
+class ImageLevel(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("first_texel", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class MaterialRecipe(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("tex", C.c_uint32 * 4), ("rough_chan", C.c_uint32), ("metal_chan", C.c_uint32),
+                ("ior", C.c_float)]
 
 
 class Surface(C.Structure):
     _fields_ = [("material", C.c_uint32), ("flags", C.c_uint32), ("inside_medium", C.c_int32),
-                ("emissive", C.c_float * 3), ("pad", C.c_float * 2)]
+                ("emissive", C.c_float * 3), ("normal_map", C.c_uint32), ("emissive_map", C.c_uint32)]
 
 
 class Medium(C.Structure):
@@ -117,6 +136,11 @@ class SceneDesc(C.Structure):
         ("n_lights", C.c_uint32), ("lights", C.POINTER(Light)),
         ("light_sampler", C.c_uint32), ("env_light_index", C.c_int32),
         ("light_alias", AliasTable), ("env", Env),
+        ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture)),
+        ("n_images", C.c_uint32), ("images", C.POINTER(Image)),
+        ("n_image_levels", C.c_uint32), ("image_levels", C.POINTER(ImageLevel)),
+        ("n_texels", C.c_uint32), ("texels", C.POINTER(C.c_uint32)),
+        ("n_material_recipes", C.c_uint32), ("material_recipes", C.POINTER(MaterialRecipe)),
     ]
 
 
@@ -251,6 +275,9 @@ class Scene:
             "spheres": (d.spheres, d.n_spheres, Sphere), "surfaces": (d.surfaces, d.n_surfaces, Surface),
             "materials": (d.materials, d.n_materials, Material), "mediums": (d.mediums, d.n_mediums, Medium),
             "lights": (d.lights, d.n_lights, Light),
+            "textures": (d.textures, d.n_textures, Texture), "images": (d.images, d.n_images, Image),
+            "image_levels": (d.image_levels, d.n_image_levels, ImageLevel), "texels": (d.texels, d.n_texels, C.c_uint32),
+            "material_recipes": (d.material_recipes, d.n_material_recipes, MaterialRecipe),
         }
         ptr, n, ty = table[field]
         if n == 0:
@@ -425,6 +452,16 @@ def write_png(path: str, film: np.ndarray) -> None:
     rgb8 = film_to_rgb8(film)
     h, w = rgb8.shape[:2]
     _check_host(host_lib().spt_host_write_png(os.fspath(path).encode(), rgb8.ctypes.data, w, h))
+
+
+def read_png(path: str) -> np.ndarray:
+    """(h, w, 4) uint8 RGBA as `image::open` + `get_pixel` present an image texture file."""
+    w, h = C.c_uint32(), C.c_uint32()
+    ptr = C.POINTER(C.c_uint32)()
+    _check_host(host_lib().spt_host_read_png(os.fspath(path).encode(), C.byref(w), C.byref(h), C.byref(ptr)))
+    arr = np.ctypeslib.as_array(ptr, shape=(h.value, w.value)).copy()
+    host_lib().spt_host_free(ptr)
+    return arr.view(np.uint8).reshape(h.value, w.value, 4)
 
 
 def read_exr(path: str) -> np.ndarray:

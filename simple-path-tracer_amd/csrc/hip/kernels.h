@@ -73,6 +73,7 @@ struct RenderCtx {
     float* film;              // n_pixels * 3 running sums
     uint32_t* first_slot;     // per pixel: first sample of the pass that uses a rad slot
     float aspect, width_inv, height_inv, spp_inv;
+    float aux_dx, aux_dy;  // auxiliary-ray offsets (pt.rs:272-275), textured scenes only
     // conservative bounding sphere of all instances relative to the camera eye (primary early-out)
     f3 bs_oc;                 // sphere centre - eye
     float bs_c;               // |oc|^2 - R^2   (R inflated by 0.1 %)
@@ -276,8 +277,12 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // identical arithmetic; the specialisation only removes branches that cannot be taken, which
 // cuts the kernel from 226 to far fewer VGPRs (more waves per SIMD to hide queue latency).
 // kFirst: bounce 0, whose queue holds the compact records written by k_primary.
-template <bool kSimple, bool kFirst>
+// kFeat 0 = kSimple, 1 = the general path.
+// kFeat 2 (textured): some material parameter, normal map or emissive map is an image texture; adds
+// texcoords, the camera ray differentials of bounce 0 and the per-hit material evaluation.
+template <int kFeat, bool kFirst>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+    constexpr bool kSimple = kFeat == 0, kTex = kFeat == 2;
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
     uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
@@ -299,6 +304,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             float4 hv = rc.hits.t_v_w_prim[idx];
             DRay ray;
             float last_pdf;
+            f3 aux_xd = mk3(0, 0, 0), aux_yd = mk3(0, 0, 0);
             if (kFirst) {
                 // rebuild the constants of a camera path from the slot (see k_primary)
                 const float4 b = rc.qa.d_pdf[idx];
@@ -308,7 +314,16 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 const uint32_t strip = row_local / rc.strip_rows;
                 const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
                 rng.s = spt_rng_seed(rc.seed, j * rc.width + col, rc.pass_first + s_local);
-                if (rc.sampler != SPT_SAMPLER_RECURRENCE) {  // the pixel offsets were the first two draws
+                if (kTex) {
+                    // the auxiliary rays of generate_ray_with_aux_ray (camera/mod.rs:15-21, offsets of pt.rs:272-275)
+                    // are a function of the pixel offsets: redo the sampler draw instead of carrying 12 floats
+                    float ox, oy;
+                    pixel_offset(rc, j * rc.width + col, rc.pass_first + s_local, rng, &ox, &oy);
+                    float x = (((float)col + ox) * rc.width_inv - 0.5f) * rc.aspect;
+                    float y = ((float)(rc.height - j - 1u) + oy) * rc.height_inv - 0.5f;
+                    aux_xd = normalize((rc.cam.forward * rc.cam.half_cot + rc.cam.right * (x + rc.aux_dx)) + rc.cam.up * y);
+                    aux_yd = normalize((rc.cam.forward * rc.cam.half_cot + rc.cam.right * x) + rc.cam.up * (y + rc.aux_dy));
+                } else if (rc.sampler != SPT_SAMPLER_RECURRENCE) {  // the pixel offsets were the first two draws
                     (void)rng.next();
                     (void)rng.next();
                 }
@@ -342,7 +357,10 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
 
             DInter it;
             it.prim_type = 0u; it.prim_id = 0u;
-            if (does_hit) it = reconstruct_hit(sc, ray, h);
+            if (does_hit) {
+                it = reconstruct_hit<kTex>(sc, ray, h);
+                if (kTex && kFirst) calc_differential(it, ray, h.t, rc.cam.eye, aux_xd, rc.cam.eye, aux_yd);   // pt.rs:51-53
+            }
 
             if (!kSimple && medium >= 0) {  // pt.rs:56-96
                 const spt_medium& md = sc.mediums[medium];
@@ -360,7 +378,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     // still in the medium: in-scattering from one light sample
                     lsi = pi;
                     DLightSample ls;
-                    if (sample_light<false>(sc, lsi, rng, &ls)) {
+                    if (sample_light<false, kTex>(sc, lsi, rng, &ls)) {
                         float phase = henyey_greenstein(md.g, dot(wo, ls.dir));
                         // shadow_ray_from_medium (pt.rs:212-233): probe the last-hit basic primitive
                         // with the world-space ray, in its own object space
@@ -431,11 +449,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 } else {  // pt.rs:112-193
                     const spt_surface& sf = sc.surfaces[it.surface];
                     const uint32_t sflags = sf.flags;
-                    DMat mt = load_material(sc, sf.material);
+                    DMat mt = material_at<kTex>(sc, sf.material, it);
                     if (kSimple) mt.bxdf = SPT_BXDF_LAMBERT;
-                    DCoord coord = surface_coord(sflags, ray, it);
+                    DCoord coord = surface_coord<kTex>(sc, sf, ray, it);
                     f3 po = it.position;
-                    f3 le = mk3(sf.emissive);
+                    f3 le = surface_emissive<kTex>(sc, sf, it);
                     if (!kSimple && luminance(le) > 0.0f) {
                         float weight = 1.0f;
                         if (depth != 0u) weight = power_heuristic(last_pdf, pdf_shape_light(sc, (uint32_t)h.inst, sflags, lsi, it, h.prim));
@@ -446,7 +464,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     lsi = po;
                     if (!mat_is_delta(mt)) {
                         DLightSample ls;
-                        if (sample_light<kSimple>(sc, lsi, rng, &ls)) {
+                        if (sample_light<kSimple, kTex>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
                             f3 f = mat_eval(mt, wo, wi);
                             float mpdf = mat_pdf(mt, wo, wi);
@@ -760,6 +778,10 @@ __global__ void k_detmath(uint32_t fn, uint32_t n, const float* a, const float* 
     case 10: r = x / y; break;
     case 11: r = spt_max(x, y); break;
     case 12: r = spt_min(x, y); break;
+    case 13: r = spt_pow(x, y); break;
+    case 14: r = spt_log2(x); break;
+    case 15: r = spt_trunc(x); break;
+    case 16: r = spt_fract(x); break;
     default: r = 0.0f; break;
     }
     out[i] = r;

@@ -24,6 +24,7 @@ struct DInter {
     f3 position, normal, tangent, bitangent;  // world space
     uint32_t surface, prim_type, prim_id;
     int32_t light;
+    float uv[2], duvdx[2], duvdy[2];          // texcoords + differentials (textured scenes only, else dead)
 };
 
 SPT_DEV void sphere_frame(f3 norm, f3* tangent, f3* bitangent) {  // sphere.rs:70-82
@@ -67,12 +68,22 @@ SPT_DEV DInstance load_instance(const DScene& sc, uint32_t inst) {
     return d;
 }
 
+SPT_DEV void sphere_normal_to_texcoords(f3 p, float* uv) {  // sphere.rs:138-145
+    float theta = spt_acos(p.y);
+    float phi = spt_atan2(p.x, p.z) + SPT_PI;
+    uv[0] = phi * 0.5f * SPT_FRAC_1_PI;
+    uv[1] = theta * SPT_FRAC_1_PI;
+}
+
 // Rebuild the shading inputs of a recorded hit (t, instance, prim, v, w):
-// triangle.rs:188-212 or sphere.rs:64-83, then instance.rs:97-104.
+// triangle.rs:188-212 or sphere.rs:64-83, then instance.rs:97-104.  kTex: also the texcoords.
+template <bool kTex = false>
 SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h) {
     const DInstance in = load_instance(sc, (uint32_t)h.inst);
     DInter it;
     f3 n, tg, bt;
+    it.uv[0] = 0.0f; it.uv[1] = 0.0f;
+    it.duvdx[0] = 0.0f; it.duvdx[1] = 0.0f; it.duvdy[0] = 0.0f; it.duvdy[1] = 0.0f;
     if (in.prim_type == SPT_PRIM_SPHERE) {
         DRay orr;
         orr.o = xf_point(in.inv, ray.o);
@@ -80,17 +91,22 @@ SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h)
         float4 s = sc.spheres[in.prim_id];
         n = (point_at(orr, h.t) - mk3(s)) / s.w;
         sphere_frame(n, &tg, &bt);
+        if (kTex) sphere_normal_to_texcoords(n, it.uv);
     } else {
         const float4* A = sc.tri_attr + 9 * (uint32_t)h.prim;
-        float4 q[7];
+        float4 q[kTex ? 9 : 7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) q[k] = A[k];
-        const float* a = reinterpret_cast<const float*>(q);  // n[3][3] t[3][3] b[3][3]
+        for (int k = 0; k < (kTex ? 9 : 7); ++k) q[k] = A[k];
+        const float* a = reinterpret_cast<const float*>(q);  // n[3][3] t[3][3] b[3][3] uv[3][2]
         float v = h.v, w = h.w;
         float u = 1.0f - v - w;
         n = normalize((mk3(a) * u + mk3(a + 3) * v) + mk3(a + 6) * w);
         tg = (mk3(a + 9) * u + mk3(a + 12) * v) + mk3(a + 15) * w;
         bt = (mk3(a + 18) * u + mk3(a + 21) * v) + mk3(a + 24) * w;
+        if (kTex) {  // lerp_point2 (triangle.rs:291-302)
+            it.uv[0] = (a[27] * u + a[29] * v) + a[31] * w;
+            it.uv[1] = (a[28] * u + a[30] * v) + a[32] * w;
+        }
     }
     it.position = point_at(ray, h.t);
     it.normal = normalize((mk3(in.nrm) * n.x + mk3(in.nrm + 3) * n.y) + mk3(in.nrm + 6) * n.z);
@@ -103,18 +119,209 @@ SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h)
     return it;
 }
 
+// ---- Intersection::calc_differential (src/core/intersection.rs:28-84, 104-118) for a camera ray
+SPT_DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float* x1, float* x2) {  // columns (a00,a01), (a10,a11)
+    float det = a00 * a11 - a01 * a10;
+    if (det != 0.0f) {
+        float temp = b1 * a00 - b0 * a01;
+        *x2 = temp / det;
+        *x1 = (spt_abs(a00) > spt_abs(a01)) ? (b0 - a10 * *x2) / a00 : (b1 - a11 * *x2) / a01;
+        return true;
+    }
+    return false;
+}
+SPT_DEV void calc_differential(DInter& it, const DRay& ray, float t, f3 xo, f3 xd, f3 yo, f3 yd) {
+    f3 p = point_at(ray, t);
+    float d = dot(p, it.normal);
+    float tx = (d - dot(xo, it.normal)) / dot(xd, it.normal);
+    f3 px = xo + xd * tx;
+    float ty = (d - dot(yo, it.normal)) / dot(yd, it.normal);
+    f3 py = yo + yd * ty;
+    f3 dpdx = px - p, dpdy = py - p;
+    float bx0, bx1, by0, by1, a00, a01, a10, a11;
+    float ax = spt_abs(it.normal.x), ay = spt_abs(it.normal.y), az = spt_abs(it.normal.z);
+    if (ax >= ay && ax >= az) {
+        bx0 = dpdx.y; bx1 = dpdx.z; by0 = dpdy.y; by1 = dpdy.z;
+        a00 = it.tangent.y; a01 = it.tangent.z; a10 = it.bitangent.y; a11 = it.bitangent.z;
+    } else if (ay >= az) {
+        bx0 = dpdx.z; bx1 = dpdx.x; by0 = dpdy.z; by1 = dpdy.x;
+        a00 = it.tangent.z; a01 = it.tangent.x; a10 = it.bitangent.z; a11 = it.bitangent.x;
+    } else {
+        bx0 = dpdx.x; bx1 = dpdx.y; by0 = dpdy.x; by1 = dpdy.y;
+        a00 = it.tangent.x; a01 = it.tangent.y; a10 = it.bitangent.x; a11 = it.bitangent.y;
+    }
+    float x1, x2;
+    if (solve_2x2(a00, a01, a10, a11, bx0, bx1, &x1, &x2)) { it.duvdx[0] = x1; it.duvdx[1] = x2; }
+    if (solve_2x2(a00, a01, a10, a11, by0, by1, &x1, &x2)) { it.duvdy[0] = x1; it.duvdy[1] = x2; }
+}
+
+// ---- textures (src/texture/*.rs) ---------------------------------------------------------------
+// The closed Texture enum is a graph; spt_scene_create compiles every node into a postfix program so
+// that the evaluation needs no recursion: scalar / image leaves push an RGBA value, binary ops and the
+// sRGB decode act on the top of a 4-deep value stack kept in registers (the host refuses deeper
+// programs).  An image leaf carries the chain of TexInputModifiers above it (outermost first), which it
+// applies to the hit's TextureInput in the reference's order before sampling.
+enum { TEXOP_SCALAR = 0, TEXOP_IMAGE = 1, TEXOP_ADD = 2, TEXOP_SUB = 3, TEXOP_MUL = 4, TEXOP_DIV = 5, TEXOP_SRGB = 6 };
+
+struct DTexIn {  // TextureInput (mod.rs:50-62) as From<&Intersection> fills it (mod.rs:143-157)
+    f3 position, normal, tangent, bitangent;
+    float uv[2], duvdx[2], duvdy[2];
+};
+SPT_DEV DTexIn tex_input(const DInter& it) {
+    DTexIn in;
+    in.position = it.position; in.normal = it.normal; in.tangent = it.tangent; in.bitangent = it.bitangent;
+    in.uv[0] = it.uv[0]; in.uv[1] = it.uv[1];
+    in.duvdx[0] = it.duvdx[0]; in.duvdx[1] = it.duvdx[1];
+    in.duvdy[0] = it.duvdy[0]; in.duvdy[1] = it.duvdy[1];
+    return in;
+}
+SPT_DEV float4 rgba_to_vec4(uint32_t px) {  // image_tex.rs:153-160
+    return make_float4((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f, (float)(px >> 24) / 255.0f);
+}
+SPT_DEV float4 v4_lerp(float4 a, float4 b, float t) {  // a * (1 - t) + b * t
+    float s = 1.0f - t;
+    return make_float4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
+}
+SPT_DEV float4 sample_bilinear(const DScene& sc, uint4 L, float u, float v) {  // image_tex.rs:102-125
+    const uint32_t* tx = sc.texels + L.z;
+    float x = u * (float)L.x;
+    int32_t x1 = spt_f2i_sat(spt_round(x));
+    int32_t x0 = (int32_t)((uint32_t)x1 - 1u);   // wrapping, as release-mode Rust
+    float xt = x - (float)x0 - 0.5f;
+    int32_t wmax = (int32_t)L.x - 1, hmax = (int32_t)L.y - 1;
+    x0 = x0 < 0 ? 0 : (x0 > wmax ? wmax : x0);
+    x1 = x1 < 0 ? 0 : (x1 > wmax ? wmax : x1);
+    float y = v * (float)L.y;
+    int32_t y1 = spt_f2i_sat(spt_round(y));
+    int32_t y0 = (int32_t)((uint32_t)y1 - 1u);
+    float yt = y - (float)y0 - 0.5f;
+    y0 = y0 < 0 ? 0 : (y0 > hmax ? hmax : y0);
+    y1 = y1 < 0 ? 0 : (y1 > hmax ? hmax : y1);
+    float4 c00 = rgba_to_vec4(tx[(uint32_t)y0 * L.x + (uint32_t)x0]), c01 = rgba_to_vec4(tx[(uint32_t)y1 * L.x + (uint32_t)x0]);
+    float4 c10 = rgba_to_vec4(tx[(uint32_t)y0 * L.x + (uint32_t)x1]), c11 = rgba_to_vec4(tx[(uint32_t)y1 * L.x + (uint32_t)x1]);
+    float4 c0 = v4_lerp(c00, c01, yt);
+    float4 c1 = v4_lerp(c10, c11, yt);
+    return v4_lerp(c0, c1, xt);
+}
+SPT_DEV float4 sample_trilinear(const DScene& sc, uint32_t image, float u, float v, const float* duvdx, const float* duvdy) {  // image_tex.rs:127-151
+    const uint2 im = sc.images[image];
+    if (im.y == 0u) return make_float4(0, 0, 0, 0);
+    const uint4* lv = sc.image_levels + im.x;
+    const uint4 l_base = lv[0];
+    float sx = (float)l_base.x, sy = (float)l_base.y;
+    float dxx = duvdx[0] * sx, dxy = duvdx[1] * sy, dyx = duvdy[0] * sx, dyy = duvdy[1] * sy;
+    float lx = spt_sqrt(dxx * dxx + dxy * dxy), ly = spt_sqrt(dyx * dyx + dyy * dyy);
+    float level = spt_clamp(spt_log2(spt_max(lx, ly) + 0.001f), 0.0f, (float)(im.y - 1u));
+    uint32_t l0 = spt_f2u_sat(spt_floor(level));
+    if (l0 + 1u == im.y) return sample_bilinear(sc, lv[l0], u, v);
+    float lt = level - (float)l0;
+    float4 c0 = sample_bilinear(sc, lv[l0], u, v), c1 = sample_bilinear(sc, lv[l0 + 1u], u, v);
+    return v4_lerp(c0, c1, lt);
+}
+SPT_DEV float srgb_to_linear(float sv) {  // srgb_tex.rs:53-59
+    return (sv <= 0.04045f) ? sv / 12.92f : spt_pow((sv + 0.055f) / 1.055f, 2.4f);
+}
+// TextureInput::value_vec2_wrapped (mod.rs:73-141) of the input after the modifier chain
+SPT_DEV float tex_wrap(float x, int32_t wrap) {
+    switch (wrap) {
+    case SPT_TEXWRAP_REPEAT: {
+        float fr = spt_fract(x);
+        return (x >= 0.0f) ? fr : 1.0f + fr;
+    }
+    case SPT_TEXWRAP_MIRROR_REPEAT: {
+        float fr = spt_fract(x);
+        float xn = (x >= 0.0f) ? fr : 1.0f + fr;
+        return (spt_f2i_sat(x) % 2 == 0) ? xn : 1.0f - xn;
+    }
+    case SPT_TEXWRAP_CLAMP: return spt_clamp(x, 0.0f, 1.0f);
+    default: return spt_abs(spt_clamp(x, 0.0f, 1.0f));
+    }
+}
+SPT_DEV float4 tex_image_leaf(const DScene& sc, const DTexIn& base, uint32_t image, uint32_t chain_first, uint32_t chain_len) {
+    DTexIn in = base;
+    int32_t mode = SPT_TEXMODE_TEXCOORDS, wrap = SPT_TEXWRAP_REPEAT;
+    for (uint32_t c = 0; c < chain_len; ++c) {  // TexInputModifier::apply_modifier (input_modifier.rs:35-50)
+        const float4* T = sc.textures + 4u * sc.tex_chain[chain_first + c];
+        const float4 t1 = T[1], t2 = T[2], t3 = T[3];   // (value.xyz, mode) (wrap, tiling.xyz) (offset.xyz, -)
+        const f3 tl = mk3(t2.y, t2.z, t2.w), of = mk3(t3.x, t3.y, t3.z);
+        in.position = mk3(in.position.x * tl.x + of.x, in.position.y * tl.y + of.y, in.position.z * tl.z + of.z);
+        in.normal = mk3(in.normal.x * tl.x + of.x, in.normal.y * tl.y + of.y, in.normal.z * tl.z + of.z);
+        in.tangent = mk3(in.tangent.x * tl.x + of.x, in.tangent.y * tl.y + of.y, in.tangent.z * tl.z + of.z);
+        in.bitangent = mk3(in.bitangent.x * tl.x + of.x, in.bitangent.y * tl.y + of.y, in.bitangent.z * tl.z + of.z);
+        in.uv[0] = in.uv[0] * tl.x + of.x; in.uv[1] = in.uv[1] * tl.y + of.y;
+        in.duvdx[0] = in.duvdx[0] * tl.x; in.duvdx[1] = in.duvdx[1] * tl.y;
+        in.duvdy[0] = in.duvdy[0] * tl.x; in.duvdy[1] = in.duvdy[1] * tl.y;
+        const int32_t m = __float_as_int(t1.w), w = __float_as_int(t2.x);
+        if (m >= 0) mode = m;
+        if (w >= 0) wrap = w;
+    }
+    float vx, vy;
+    switch (mode) {
+    case SPT_TEXMODE_TEXCOORDS: vx = in.uv[0]; vy = in.uv[1]; break;
+    case SPT_TEXMODE_POSITION: vx = in.position.x; vy = in.position.y; break;
+    case SPT_TEXMODE_NORMAL: vx = in.normal.x; vy = in.normal.y; break;
+    case SPT_TEXMODE_TANGENT: vx = in.tangent.x; vy = in.tangent.y; break;
+    case SPT_TEXMODE_BITANGENT: vx = in.bitangent.x; vy = in.bitangent.y; break;
+    default: vx = 0.0f; vy = 0.0f; break;
+    }
+    return sample_trilinear(sc, image, tex_wrap(vx, wrap), tex_wrap(vy, wrap), in.duvdx, in.duvdy);
+}
+// color_at / float_at of texture `node` as one RGBA value (ScalarTex alpha = 1, SrgbTex keeps alpha)
+SPT_DEV float4 tex_eval(const DScene& sc, uint32_t node, const DTexIn& in) {
+    const uint2 root = sc.tex_root[node];
+    float4 v0 = make_float4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;   // value stack, v0 = top
+    for (uint32_t pc = root.x; pc < root.x + root.y; ++pc) {
+        const uint4 ins = sc.tex_prog[pc];
+        if (ins.x <= TEXOP_IMAGE) {
+            float4 nv;
+            if (ins.x == TEXOP_SCALAR) nv = make_float4(__uint_as_float(ins.y), __uint_as_float(ins.z), __uint_as_float(ins.w), 1.0f);
+            else nv = tex_image_leaf(sc, in, ins.y, ins.z, ins.w);
+            v3 = v2; v2 = v1; v1 = v0; v0 = nv;
+        } else if (ins.x == TEXOP_SRGB) {
+            v0 = make_float4(srgb_to_linear(v0.x), srgb_to_linear(v0.y), srgb_to_linear(v0.z), v0.w);
+        } else {
+            float4 a = v1, b = v0, r;   // a (op) b: t1 was pushed first
+            if (ins.x == TEXOP_ADD) r = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            else if (ins.x == TEXOP_SUB) r = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+            else if (ins.x == TEXOP_MUL) r = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+            else r = make_float4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w);
+            v0 = r; v1 = v2; v2 = v3;
+        }
+    }
+    return v0;
+}
+SPT_DEV f3 tex_color(const DScene& sc, uint32_t node, const DTexIn& in) { return mk3(tex_eval(sc, node, in)); }
+SPT_DEV float tex_float(const DScene& sc, uint32_t node, const DTexIn& in, uint32_t chan) {
+    float4 c = tex_eval(sc, node, in);
+    return chan == SPT_CHAN_R ? c.x : (chan == SPT_CHAN_G ? c.y : (chan == SPT_CHAN_B ? c.z : c.w));
+}
+// Surface::emissive (surface.rs:49-55)
+template <bool kTex>
+SPT_DEV f3 surface_emissive(const DScene& sc, const spt_surface& sf, const DInter& it) {
+    f3 e = mk3(sf.emissive);
+    if (kTex && sf.emissive_map) e = e * tex_color(sc, sf.emissive_map - 1u, tex_input(it));
+    return e;
+}
+
 // ---- Coordinate (coord.rs:10-59)
 struct DCoord {
     f3 xw, yw, zw, hemi;
     SPT_DEV f3 to_local(f3 w) const { return mk3(dot(xw, w), dot(yw, w), dot(zw, w)); }
     SPT_DEV f3 to_world(f3 l) const { return (xw * l.x + yw * l.y) + zw * l.z; }
 };
-// Surface::coord without normal map (surface.rs:65-95) + Coordinate::from_tangent_normal
-SPT_DEV DCoord surface_coord(uint32_t surf_flags, const DRay& ray, const DInter& it) {
+// Surface::coord (surface.rs:65-95) + Coordinate::from_tangent_normal
+template <bool kTex = false>
+SPT_DEV DCoord surface_coord(const DScene& sc, const spt_surface& sf, const DRay& ray, const DInter& it) {
+    f3 shade_normal = it.normal;
+    if (kTex && sf.normal_map) {
+        f3 value = tex_color(sc, sf.normal_map - 1u, tex_input(it));
+        f3 local = normalize(value * 2.0f - gray(1.0f));
+        shade_normal = normalize((local.x * normalize(it.tangent) + local.y * normalize(it.bitangent)) + local.z * it.normal);
+    }
     bool hit_back = dot(ray.d, it.normal) > 0.0f;
-    bool ds = (surf_flags & SPT_SURF_DOUBLE_SIDED) != 0;
+    bool ds = (sf.flags & SPT_SURF_DOUBLE_SIDED) != 0;
     DCoord c;
-    c.zw = (ds && hit_back) ? -it.normal : it.normal;
+    c.zw = (ds && hit_back) ? -shade_normal : shade_normal;
     c.yw = normalize(cross(c.zw, it.tangent));
     c.xw = cross(c.yw, c.zw);
     c.hemi = hit_back ? -it.normal : it.normal;
@@ -252,6 +459,77 @@ SPT_DEV DMat load_material(const DScene& sc, uint32_t m) {
     d.c2 = mk3(c.z, c.w, e.x);
     d.fresnel = __float_as_uint(e.y);
     d.substrate = __float_as_uint(e.z);
+    return d;
+}
+SPT_DEV float fresnel_moment1(float eta) {  // src/bxdf/util.rs:123-134
+    float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
+    if (eta < 1.0f) return 0.45966f - 1.73965f * eta + 3.37668f * eta2 - 3.904945f * eta3 + 2.49277f * eta4 - 0.68441f * eta5;
+    return -4.61686f + 11.1136f * eta - 10.4646f * eta2 + 5.11455f * eta3 - 1.27198f * eta4 + 0.12746f * eta5;
+}
+// MaterialT::bxdf_context at a hit (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs):
+// constant materials were folded by the loader; a material with an image-backed parameter carries a recipe.
+template <bool kTex>
+SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
+    DMat d = load_material(sc, m);
+    if (!kTex) return d;
+    const uint32_t recipe = __float_as_uint(reinterpret_cast<const float4*>(sc.materials + m)[3].w);
+    if (recipe == 0u) return d;
+    const uint4 r0 = sc.recipes[2u * (recipe - 1u)], r1 = sc.recipes[2u * (recipe - 1u) + 1u];   // (type, tex0..2) (tex3, rough_chan, metal_chan, ior)
+    const float ior = __uint_as_float(r1.w);
+    const DTexIn in = tex_input(it);
+    d.c0 = mk3(0, 0, 0); d.c1 = mk3(0, 0, 0); d.c2 = mk3(0, 0, 0);
+    d.ax = 0.0f; d.ay = 0.0f; d.ior = 0.0f; d.fresnel = 0u; d.substrate = 0u;
+    bool specular = false;
+    if (r0.x != SPT_MAT_LAMBERT) {
+        float rx = tex_float(sc, r0.w, in, r1.y), ry = tex_float(sc, r1.x, in, r1.y);
+        const bool squared = r0.x != SPT_MAT_PLASTIC;   // plastic.rs:64-65 hands the texture value over as is
+        d.ax = squared ? rx * rx : rx;
+        d.ay = squared ? ry * ry : ry;
+        specular = d.ax < 0.0001f || d.ay < 0.0001f;
+    }
+    switch (r0.x) {
+    case SPT_MAT_LAMBERT:
+        d.bxdf = SPT_BXDF_LAMBERT;
+        d.c0 = tex_color(sc, r0.y, in);
+        break;
+    case SPT_MAT_CONDUCTOR:
+        d.c0 = tex_color(sc, r0.y, in);
+        d.c1 = tex_color(sc, r0.z, in);
+        d.bxdf = specular ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
+        break;
+    case SPT_MAT_DIELECTRIC:
+        d.ior = ior;
+        d.bxdf = specular ? SPT_BXDF_SPECULAR_DIELECTRIC : SPT_BXDF_MICROFACET_DIELECTRIC;
+        break;
+    case SPT_MAT_PLASTIC: {  // Diffuse::new (substrate.rs:127-137)
+        f3 albedo = tex_color(sc, r0.y, in);
+        d.ior = ior;
+        d.bxdf = specular ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        d.fresnel = SPT_FRESNEL_DIELECTRIC;
+        d.substrate = SPT_SUBSTRATE_DIFFUSE;
+        d.c0 = albedo;
+        float fdr = 2.0f * fresnel_moment1(1.0f / ior);
+        d.c2 = cdiv(albedo * SPT_FRAC_1_PI, ((gray(1.0f) - albedo * fdr) * ior) * ior);
+        break;
+    }
+    case SPT_MAT_PBR_METALLIC: {  // pbr_metallic.rs:75-104
+        f3 base = tex_color(sc, r0.y, in);
+        float metallic = tex_float(sc, r0.z, in, r1.z);
+        d.c1 = metallic * base + (1.0f - metallic) * gray(0.04f);
+        d.c0 = base * (1.0f - metallic);
+        d.bxdf = specular ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        d.fresnel = SPT_FRESNEL_SCHLICK;
+        d.substrate = SPT_SUBSTRATE_LAMBERT;
+        break;
+    }
+    default:  // pbr_specular.rs:60-92
+        d.c0 = tex_color(sc, r0.y, in);
+        d.c1 = tex_color(sc, r0.z, in);
+        d.bxdf = specular ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        d.fresnel = SPT_FRESNEL_SCHLICK;
+        d.substrate = SPT_SUBSTRATE_LAMBERT;
+        break;
+    }
     return d;
 }
 SPT_DEV bool mat_is_delta(const DMat& m) {
@@ -560,13 +838,13 @@ SPT_DEV void env_lookup(const DScene& sc, float theta, float phi, f3* c_out, flo
     int32_t W = (int32_t)sc.env_w, H = (int32_t)sc.env_h;
     float x = phi * 0.5f * SPT_FRAC_1_PI * (float)sc.env_w;
     int32_t x1 = spt_f2i_sat(spt_round(x));
-    int32_t x0 = x1 - 1;
+    int32_t x0 = (int32_t)((uint32_t)x1 - 1u);   // wrapping, as release-mode Rust
     float xt = x - (float)x0 - 0.5f;
     uint32_t ux0 = (uint32_t)(x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0));
     uint32_t ux1 = (uint32_t)(x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1));
     float y = theta * SPT_FRAC_1_PI * (float)sc.env_h;
     int32_t y1 = spt_f2i_sat(spt_round(y));
-    int32_t y0 = y1 - 1;
+    int32_t y0 = (int32_t)((uint32_t)y1 - 1u);
     float yt = y - (float)y0 - 0.5f;
     uint32_t uy0 = (uint32_t)(y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0));
     uint32_t uy1 = (uint32_t)(y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1));
@@ -596,7 +874,8 @@ struct DLightSample {
 
 // Instance::sample (instance.rs:111-129) over Sphere::sample (sphere.rs:103-136) /
 // BvhAccel<Triangle>::sample (bvh.rs:293-298) + Triangle::sample (triangle.rs:224-271)
-SPT_DEV void instance_sample(const DScene& sc, const DInstance& in, DRng& rng, f3* pos, f3* nrm, float* pdf_out) {
+template <bool kTex = false>
+SPT_DEV void instance_sample(const DScene& sc, const DInstance& in, DRng& rng, f3* pos, f3* nrm, float* pdf_out, DInter* at = nullptr) {
     f3 p, n, tg, bt;
     float pdf;
     if (in.prim_type == SPT_PRIM_SPHERE) {
@@ -609,6 +888,7 @@ SPT_DEV void instance_sample(const DScene& sc, const DInstance& in, DRng& rng, f
         float sin_theta = spt_sqrt(1.0f - cos_theta * cos_theta);
         n = mk3(sin_theta * cphi, sin_theta * sphi, cos_theta);
         p = mk3(s) + n * s.w;
+        if (kTex) sphere_normal_to_texcoords(n, at->uv);
         sphere_frame(n, &tg, &bt);
         pdf = 0.25f * SPT_FRAC_1_PI;
     } else {
@@ -624,10 +904,14 @@ SPT_DEV void instance_sample(const DScene& sc, const DInstance& in, DRng& rng, f
         float w = 1.0f - u - v;
         f3 p0 = mk3(sc.tri_pos[3 * tri]), p1 = mk3(sc.tri_pos[3 * tri + 1]), p2 = mk3(sc.tri_pos[3 * tri + 2]);
         const float4* A = sc.tri_attr + 9 * tri;
-        float4 q[7];
+        float4 q[kTex ? 9 : 7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) q[k] = A[k];
+        for (int k = 0; k < (kTex ? 9 : 7); ++k) q[k] = A[k];
         const float* a = reinterpret_cast<const float*>(q);
+        if (kTex) {  // triangle.rs:258
+            at->uv[0] = (a[27] * u + a[29] * v) + a[31] * w;
+            at->uv[1] = (a[28] * u + a[30] * v) + a[32] * w;
+        }
         p = (p0 * u + p1 * v) + p2 * w;
         float area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
         n = (mk3(a) * u + mk3(a + 3) * v) + mk3(a + 6) * w;
@@ -642,6 +926,10 @@ SPT_DEV void instance_sample(const DScene& sc, const DInstance& in, DRng& rng, f
     tg = xf_vector(in.fwd, tg);
     float transformed_area = length(cross(tg, bt));
     *pdf_out = pdf * original_area / transformed_area;
+    if (kTex) {  // the sampled point as the Intersection Surface::emissive sees (no differentials)
+        at->position = *pos; at->normal = *nrm; at->tangent = tg; at->bitangent = bt;
+        at->duvdx[0] = 0.0f; at->duvdx[1] = 0.0f; at->duvdy[0] = 0.0f; at->duvdy[1] = 0.0f;
+    }
 }
 
 // Instance::pdf (instance.rs:131-141) over Triangle::pdf / Sphere::pdf
@@ -669,7 +957,7 @@ SPT_DEV float instance_pdf(const DScene& sc, uint32_t inst, const DInter& it, in
 
 // kDeltaOnly: the scene has only directional / point / spot lights (checked on the host), so the
 // area-light and environment branches are not even compiled into the kernel.
-template <bool kDeltaOnly>
+template <bool kDeltaOnly, bool kTex = false>
 SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRng& rng, DLightSample* out) {
     uint32_t type = l.type;
     if (kDeltaOnly && type > SPT_LIGHT_SPOT) type = SPT_LIGHT_DIRECTIONAL;
@@ -699,8 +987,9 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
         const spt_surface& sf = sc.surfaces[in.surface];
         f3 spos, snrm;
         float spdf;
-        instance_sample(sc, in, rng, &spos, &snrm, &spdf);
-        f3 emissive = mk3(sf.emissive);
+        DInter at;
+        instance_sample<kTex>(sc, in, rng, &spos, &snrm, &spdf, &at);
+        f3 emissive = surface_emissive<kTex>(sc, sf, at);
         f3 light_vec = spos - position;
         float dist_sqr = dot(light_vec, light_vec);
         float dist = spt_sqrt(dist_sqr);
@@ -735,19 +1024,19 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
 }
 
 // sample_light (uniform.rs:28-41, power_is.rs:49-59); false if the scene has no light
-template <bool kDeltaOnly>
+template <bool kDeltaOnly, bool kTex = false>
 SPT_DEV bool sample_light(const DScene& sc, f3 position, DRng& rng, DLightSample* out) {
     if (sc.n_lights == 0) return false;
     if (sc.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) {
         float pr;
         uint32_t index = alias_sample(sc.light_props, sc.light_u, sc.light_k, sc.n_lights, rng.next(), &pr);
-        light_sample<kDeltaOnly>(sc, sc.lights[index], position, rng, out);
+        light_sample<kDeltaOnly, kTex>(sc, sc.lights[index], position, rng, out);
         out->pdf = pr * out->pdf;
     } else {
         float fi = rng.next() * (float)sc.n_lights;
         uint32_t index = spt_f2u_sat(fi);
         if (index > sc.n_lights - 1) index = sc.n_lights - 1;
-        light_sample<kDeltaOnly>(sc, sc.lights[index], position, rng, out);
+        light_sample<kDeltaOnly, kTex>(sc, sc.lights[index], position, rng, out);
         out->pdf = out->pdf * (1.0f / (float)sc.n_lights);
     }
     return true;

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -289,7 +290,9 @@ struct spt_scene {
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     bool bs_valid = false;
-    bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<true>)
+    bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
+    bool textured = false;  // a material recipe, normal map or emissive map samples textures per hit (k_shade<2, .>)
+    DeviceBuffer textures, tex_prog, tex_root, tex_chain, images, image_levels, texels, recipes;
     std::vector<hipEvent_t> events;
     ~spt_scene() {
         (void)hipSetDevice(device);
@@ -341,8 +344,44 @@ void validate(const spt_scene_desc& s) {
         if (s.surfaces[i].inside_medium >= (int32_t)s.n_mediums) fail(SPT_ERR_INVALID_ARG, "scene desc: surface medium out of range");
         if (s.surfaces[i].inside_medium >= 254) fail(SPT_ERR_UNSUPPORTED, "scene desc: more than 254 mediums");
     }
-    for (uint32_t i = 0; i < s.n_materials; ++i)
+    for (uint32_t i = 0; i < s.n_materials; ++i) {
         if (s.materials[i].bxdf > SPT_BXDF_SPECULAR_PLASTIC) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown bxdf tag");
+        if (s.materials[i].recipe > s.n_material_recipes) fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe out of range");
+    }
+    need(s.textures, s.n_textures, "textures");
+    need(s.images, s.n_images, "images");
+    need(s.image_levels, s.n_image_levels, "image_levels");
+    need(s.texels, s.n_texels, "texels");
+    need(s.material_recipes, s.n_material_recipes, "material_recipes");
+    for (uint32_t i = 0; i < s.n_images; ++i) {
+        const spt_image& im = s.images[i];
+        if (im.n_levels == 0 || (uint64_t)im.first_level + im.n_levels > s.n_image_levels) fail(SPT_ERR_INVALID_ARG, "scene desc: image level range out of bounds");
+    }
+    for (uint32_t i = 0; i < s.n_image_levels; ++i) {
+        const spt_image_level& L = s.image_levels[i];
+        if (L.width == 0 || L.height == 0 || (uint64_t)L.width * L.height > 0x7fffffffull ||
+            (uint64_t)L.first_texel + (uint64_t)L.width * L.height > s.n_texels)
+            fail(SPT_ERR_INVALID_ARG, "scene desc: image level texels out of bounds");
+    }
+    for (uint32_t i = 0; i < s.n_textures; ++i) {
+        const spt_texture& t = s.textures[i];
+        if (t.type > SPT_TEX_MODIFIER) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown texture type");
+        if (t.type == SPT_TEX_IMAGE && t.image >= s.n_images) fail(SPT_ERR_INVALID_ARG, "scene desc: texture image out of range");
+        const bool unary = t.type == SPT_TEX_SRGB || t.type == SPT_TEX_MODIFIER, binary = t.type >= SPT_TEX_ADD && t.type <= SPT_TEX_DIV;
+        if ((unary || binary) && t.a >= i) fail(SPT_ERR_INVALID_ARG, "scene desc: texture child must precede its parent");
+        if (binary && t.b >= i) fail(SPT_ERR_INVALID_ARG, "scene desc: texture child must precede its parent");
+        if (t.type == SPT_TEX_MODIFIER && (t.mode > SPT_TEXMODE_BITANGENT || t.wrap > SPT_TEXWRAP_MIRROR_CLAMP))
+            fail(SPT_ERR_INVALID_ARG, "scene desc: bad texture input mode / wrap");
+    }
+    for (uint32_t i = 0; i < s.n_material_recipes; ++i) {
+        const spt_material_recipe& r = s.material_recipes[i];
+        if (r.type > SPT_MAT_PBR_SPECULAR || r.rough_chan > SPT_CHAN_A || r.metal_chan > SPT_CHAN_A) fail(SPT_ERR_INVALID_ARG, "scene desc: bad material recipe");
+        for (int k = 0; k < 4; ++k)
+            if (r.tex[k] >= s.n_textures) fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe texture out of range");
+    }
+    for (uint32_t i = 0; i < s.n_surfaces; ++i)
+        if (s.surfaces[i].normal_map > s.n_textures || s.surfaces[i].emissive_map > s.n_textures)
+            fail(SPT_ERR_INVALID_ARG, "scene desc: surface map out of range");
     for (uint32_t i = 0; i < s.n_lights; ++i) {
         const spt_light& l = s.lights[i];
         if (l.type > SPT_LIGHT_ENV) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown light type");
@@ -542,6 +581,80 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             float lum = 0.299f * sf.emissive[0] + 0.587f * sf.emissive[1] + 0.114f * sf.emissive[2];
             simple = simple && sf.inside_medium < 0 && !(lum > 0.0f);
         }
+        // image textures: only scenes that sample one per hit pay for the k_shade<2, .> variant
+        bool textured = false;
+        for (uint32_t i = 0; i < s.n_materials; ++i) textured = textured || s.materials[i].recipe != 0;
+        for (uint32_t i = 0; i < s.n_surfaces; ++i) textured = textured || s.surfaces[i].normal_map != 0 || s.surfaces[i].emissive_map != 0;
+        sc->textured = textured;
+        if (textured) {
+            simple = false;
+            // postfix program per texture node (see shading.h "textures"); children precede parents, so a
+            // node's program is its children's programs followed by its own op
+            struct Prog { std::vector<uint4> code; uint32_t depth; };
+            std::vector<uint32_t> chain_pool;
+            std::vector<uint4> prog_pool;
+            std::vector<uint2> roots(s.n_textures);
+            // emit(node, chain): instructions of `node` evaluated under the modifier chain `chain`
+            std::function<uint32_t(uint32_t, std::vector<uint32_t>&, std::vector<uint4>&)> emit =
+                [&](uint32_t node, std::vector<uint32_t>& chain, std::vector<uint4>& out) -> uint32_t {
+                const spt_texture& t = s.textures[node];
+                auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+                switch (t.type) {
+                case SPT_TEX_SCALAR:
+                    out.push_back(make_uint4(TEXOP_SCALAR, bits(t.value[0]), bits(t.value[1]), bits(t.value[2])));
+                    return 1u;
+                case SPT_TEX_IMAGE: {
+                    const uint32_t first = (uint32_t)chain_pool.size();
+                    chain_pool.insert(chain_pool.end(), chain.begin(), chain.end());
+                    out.push_back(make_uint4(TEXOP_IMAGE, t.image, first, (uint32_t)chain.size()));
+                    return 1u;
+                }
+                case SPT_TEX_SRGB: {
+                    const uint32_t d = emit(t.a, chain, out);
+                    out.push_back(make_uint4(TEXOP_SRGB, 0, 0, 0));
+                    return d;
+                }
+                case SPT_TEX_MODIFIER: {
+                    chain.push_back(node);
+                    const uint32_t d = emit(t.a, chain, out);
+                    chain.pop_back();
+                    return d;
+                }
+                default: {
+                    const uint32_t da = emit(t.a, chain, out);
+                    const uint32_t db = emit(t.b, chain, out);
+                    out.push_back(make_uint4(TEXOP_ADD + (t.type - SPT_TEX_ADD), 0, 0, 0));
+                    return std::max(da, db + 1u);
+                }
+                }
+            };
+            for (uint32_t i = 0; i < s.n_textures; ++i) {
+                std::vector<uint32_t> chain;
+                std::vector<uint4> code;
+                const uint32_t depth = emit(i, chain, code);
+                if (depth > 4u) fail(SPT_ERR_UNSUPPORTED, "texture expression needs more than 4 pending values");
+                if (prog_pool.size() + code.size() > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "texture programs too large");
+                roots[i] = make_uint2((uint32_t)prog_pool.size(), (uint32_t)code.size());
+                prog_pool.insert(prog_pool.end(), code.begin(), code.end());
+            }
+            if (chain_pool.empty()) chain_pool.push_back(0u);
+            sc->textures.upload(s.textures, s.n_textures);
+            sc->tex_prog.upload(prog_pool.data(), prog_pool.size());
+            sc->tex_root.upload(roots.data(), roots.size());
+            sc->tex_chain.upload(chain_pool.data(), chain_pool.size());
+            sc->images.upload(s.images, s.n_images);
+            sc->image_levels.upload(s.image_levels, s.n_image_levels);
+            sc->texels.upload(s.texels, s.n_texels);
+            sc->recipes.upload(s.material_recipes, s.n_material_recipes);
+            d.textures = sc->textures.as<float4>();
+            d.tex_prog = sc->tex_prog.as<uint4>();
+            d.tex_root = sc->tex_root.as<uint2>();
+            d.tex_chain = sc->tex_chain.as<uint32_t>();
+            d.images = sc->images.as<uint2>();
+            d.image_levels = sc->image_levels.as<uint4>();
+            d.texels = sc->texels.as<uint32_t>();
+            d.recipes = sc->recipes.as<uint4>();
+        }
         sc->simple = simple;
         if (s.n_instances) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -675,6 +788,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         rc.width_inv = 1.0f / (float)p.width;           // pt.rs:250-251
         rc.height_inv = 1.0f / (float)p.height;
         rc.spp_inv = 1.0f / (float)p.spp;
+        {   // pt.rs:253-254, 272-275
+            const float spp_sqrt_inv = 1.0f / std::sqrt((float)p.spp);
+            rc.aux_dx = rc.aspect * rc.width_inv * spp_sqrt_inv;
+            rc.aux_dy = rc.height_inv * spp_sqrt_inv;
+        }
         {
             double oc[3], d2 = 0;
             for (int k = 0; k < 3; ++k) { oc[k] = sc->bs_center[k] - (double)cam->eye[k]; d2 += oc[k] * oc[k]; }
@@ -734,11 +852,14 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             for (uint32_t b = 0; b < p.max_depth; ++b) {
                 begin(SPT_K_SHADE);
                 if (sc->simple) {
-                    if (b == 0) hipLaunchKernelGGL((k_shade<true, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                    else hipLaunchKernelGGL((k_shade<true, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    if (b == 0) hipLaunchKernelGGL((k_shade<0, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    else hipLaunchKernelGGL((k_shade<0, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                } else if (!sc->textured) {
+                    if (b == 0) hipLaunchKernelGGL((k_shade<1, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    else hipLaunchKernelGGL((k_shade<1, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
                 } else {
-                    if (b == 0) hipLaunchKernelGGL((k_shade<false, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                    else hipLaunchKernelGGL((k_shade<false, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    if (b == 0) hipLaunchKernelGGL((k_shade<2, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
+                    else hipLaunchKernelGGL((k_shade<2, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
                 }
                 end();
                 begin(SPT_K_SHADOW);

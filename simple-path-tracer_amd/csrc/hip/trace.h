@@ -50,6 +50,15 @@ struct DScene {
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
     uint32_t tlas_root;        // ref of the TLAS root (wide-node index or leaf ref)
     float tlas_lo[3], tlas_hi[3];  // its box
+    // image textures (k_shade<2, .> only; all null otherwise), see shading.h "textures"
+    const float4* textures;        // 4 x float4 per spt_texture node
+    const uint4* tex_prog;         // postfix programs, one instruction per uint4
+    const uint2* tex_root;         // per texture node: (first instruction, count)
+    const uint32_t* tex_chain;     // modifier node ids, outermost first, per image leaf
+    const uint2* images;           // (first_level, n_levels)
+    const uint4* image_levels;     // (width, height, first_texel, -)
+    const uint32_t* texels;        // RGBA8
+    const uint4* recipes;          // 2 x uint4 per spt_material_recipe
 };
 
 struct DHit {

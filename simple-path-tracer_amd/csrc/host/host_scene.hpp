@@ -26,6 +26,11 @@ struct HostScene {
     std::vector<spt_surface> surfaces;
     std::vector<spt_material> materials;
     std::vector<spt_medium> mediums;
+    std::vector<spt_texture> textures;
+    std::vector<spt_image> images;
+    std::vector<spt_image_level> image_levels;
+    std::vector<uint32_t> texels;
+    std::vector<spt_material_recipe> material_recipes;
     std::vector<spt_light> lights;
     std::vector<float> light_props, light_u;
     std::vector<uint32_t> light_k;
@@ -42,5 +47,6 @@ struct HostScene {
 };
 
 HostScene* load_scene_file(const std::string& path);
+void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
 
 }  // namespace spt_host

@@ -69,6 +69,137 @@ void put_attr(std::vector<uint8_t>& o, const char* name, const char* type, const
 
 }  // namespace
 
+namespace spt_host {
+
+// PNG -> RGBA8 as `image::open(path)` + `DynamicImage::get_pixel` present it (src/core/loader.rs:366-371,
+// src/texture/image_tex.rs:153-160): gray -> (l,l,l,255), RGB -> a = 255, palette / tRNS expanded,
+// 16-bit samples rounded to 8 bits as (c + 128) / 257.  Non-interlaced files only.
+void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw HostError(SPT_HOST_ERR_IO, "can't read image '" + path + "'");
+    std::vector<uint8_t> d;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    std::fclose(f);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0)
+        throw HostError(SPT_HOST_ERR_UNSUPPORTED, "image '" + path + "': only PNG files are decoded (JPEG decoding is not bit-reproducible across decoders; convert the asset)");
+    auto be32 = [&](size_t p) { return ((uint32_t)d[p] << 24) | ((uint32_t)d[p + 1] << 16) | ((uint32_t)d[p + 2] << 8) | (uint32_t)d[p + 3]; };
+    uint32_t w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    size_t p = 8;
+    bool seen_end = false;
+    while (p + 12 <= d.size()) {
+        uint32_t len = be32(p);
+        if (p + 12 + (size_t)len > d.size()) throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': truncated chunk");
+        std::string type((const char*)&d[p + 4], 4);
+        const uint8_t* body = &d[p + 8];
+        if (be32(p + 8 + len) != (uint32_t)crc32(0L, &d[p + 4], (uInt)(len + 4))) throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': CRC mismatch in " + type);
+        if (type == "IHDR") {
+            if (len != 13) throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': bad IHDR");
+            w = be32(p + 8); h = be32(p + 12);
+            depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (type == "PLTE") {
+            plte.assign(body, body + len);
+        } else if (type == "tRNS") {
+            trns.assign(body, body + len);
+        } else if (type == "IDAT") {
+            idat.insert(idat.end(), body, body + len);
+        } else if (type == "IEND") {
+            seen_end = true;
+            break;
+        }
+        p += 12 + (size_t)len;
+    }
+    if (!seen_end || w == 0 || h == 0) throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': missing IHDR / IEND");
+    if (interlace) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "png '" + path + "': interlaced files are not supported");
+    uint32_t channels;
+    switch (ctype) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': bad colour type");
+    }
+    const bool depth_ok = (ctype == 0) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : (ctype == 3) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                       : (depth == 8 || depth == 16);
+    if (!depth_ok) throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': bad bit depth");
+    if ((uint64_t)w * h > 0x3fffffffull) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "png '" + path + "': image too large");
+    const size_t bpp_bits = (size_t)channels * depth;
+    const size_t stride = ((size_t)w * bpp_bits + 7) / 8;
+    const size_t fbpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;   // filter distance in bytes
+    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    uLongf dl = (uLongf)raw.size();
+    if (uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size()) != Z_OK || dl != raw.size())
+        throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': zlib inflate failed");
+    // undo the scanline filters in place
+    std::vector<uint8_t> zero(stride, 0);
+    for (uint32_t y = 0; y < h; ++y) {
+        uint8_t* row = &raw[(stride + 1) * (size_t)y + 1];
+        const uint8_t* up = y ? &raw[(stride + 1) * (size_t)(y - 1) + 1] : zero.data();
+        const uint8_t ft = row[-1];
+        for (size_t x = 0; x < stride; ++x) {
+            int a = x >= fbpp ? row[x - fbpp] : 0, b = up[x], c = x >= fbpp ? up[x - fbpp] : 0, pred;
+            switch (ft) {
+            case 0: pred = 0; break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: {
+                int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                break;
+            }
+            default: throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': bad filter type");
+            }
+            row[x] = (uint8_t)(row[x] + pred);
+        }
+    }
+    auto sample = [&](const uint8_t* row, size_t i) -> uint32_t {   // i-th sample of the row, raw value
+        if (depth == 8) return row[i];
+        if (depth == 16) return ((uint32_t)row[2 * i] << 8) | row[2 * i + 1];
+        size_t bit = i * depth;
+        return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+    };
+    auto to8 = [&](uint32_t v) -> uint32_t {
+        if (depth == 8) return v;
+        if (depth == 16) return (v + 128u) / 257u;
+        return v * 255u / ((1u << depth) - 1u);
+    };
+    texels->assign((size_t)w * h, 0u);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* row = &raw[(stride + 1) * (size_t)y + 1];
+        for (uint32_t x = 0; x < w; ++x) {
+            uint32_t r, g, b, a = 255u;
+            if (ctype == 3) {
+                uint32_t i = sample(row, x);
+                if ((size_t)i * 3 + 2 >= plte.size()) throw HostError(SPT_HOST_ERR_PARSE, "png '" + path + "': palette index out of range");
+                r = plte[3 * i]; g = plte[3 * i + 1]; b = plte[3 * i + 2];
+                if (i < trns.size()) a = trns[i];
+            } else if (ctype == 0 || ctype == 4) {
+                uint32_t v = sample(row, (size_t)x * channels);
+                r = g = b = to8(v);
+                if (ctype == 4) a = to8(sample(row, (size_t)x * 2 + 1));
+                else if (trns.size() >= 2 && v == (((uint32_t)trns[0] << 8) | trns[1])) a = 0u;
+            } else {
+                uint32_t v0 = sample(row, (size_t)x * channels), v1 = sample(row, (size_t)x * channels + 1), v2 = sample(row, (size_t)x * channels + 2);
+                r = to8(v0); g = to8(v1); b = to8(v2);
+                if (ctype == 6) a = to8(sample(row, (size_t)x * 4 + 3));
+                else if (trns.size() >= 6 && v0 == (((uint32_t)trns[0] << 8) | trns[1]) && v1 == (((uint32_t)trns[2] << 8) | trns[3]) &&
+                         v2 == (((uint32_t)trns[4] << 8) | trns[5])) a = 0u;
+            }
+            (*texels)[(size_t)y * w + x] = r | (g << 8) | (b << 16) | (a << 24);
+        }
+    }
+    *width = w;
+    *height = h;
+}
+
+}  // namespace spt_host
+
 extern "C" {
 
 void spt_host_free(void* p) { std::free(p); }
@@ -270,6 +401,22 @@ spt_status spt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t wi
     std::fclose(f);
     if (wr != o.size()) { spt_host::set_error("short write"); return SPT_HOST_ERR_IO; }
     return SPT_OK;
+}
+
+spt_status spt_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out) {
+    try {
+        if (!path || !width || !height || !rgba8_out) throw HostError(SPT_ERR_INVALID_ARG, "read_png: null argument");
+        std::vector<uint32_t> t;
+        spt_host::read_png_rgba8(path, width, height, &t);
+        uint32_t* out = (uint32_t*)std::malloc(t.size() * 4);
+        if (!out) throw HostError(SPT_HOST_ERR_IO, "read_png: out of memory");
+        std::memcpy(out, t.data(), t.size() * 4);
+        *rgba8_out = out;
+        return SPT_OK;
+    } catch (const HostError& e) {
+        spt_host::set_error(e.msg);
+        return e.code;
+    }
 }
 
 }  // extern "C"

@@ -120,6 +120,13 @@ class Params {
         visited_.insert(k);
         return out;
     }
+    std::array<float, 2> get_float2_or(const std::string& k, std::array<float, 2> fb) {
+        auto it = vals_.find(k);
+        std::array<float, 2> out;
+        if (it == vals_.end() || !float_vec(it->second, 2, out.data())) return fb;
+        visited_.insert(k);
+        return out;
+    }
     // get_matrix (loader.rs:307-335): 16 values column-major; non-Float entries keep identity.
     Affine get_matrix(const std::string& k) {
         const JsonValue* v = find(k);
@@ -304,7 +311,11 @@ struct SurfaceRec { uint32_t index; bool emissive; };
 struct SceneBuilder {
     HostScene& hs;
     std::string path;
-    std::map<std::string, V3> textures;               // scalar-valued (constant-folded)
+    // a named texture = a node of hs.textures; `constant` ones (no image below them) are folded to `value`
+    struct TexInfo { uint32_t node; bool constant; V3 value; };
+    std::map<std::string, TexInfo> textures;
+    std::map<std::string, uint32_t> image_ids;        // by resolved file name: one mip pyramid per file
+    bool any_textured = false;                        // a material / surface samples an image texture per hit
     std::map<std::string, uint32_t> materials, surfaces, mediums;
     std::map<std::string, PrimRec> prims;
     std::vector<V3> avg_emissive;                     // per surface
@@ -339,10 +350,85 @@ struct SceneBuilder {
         }
     }
 
-    V3 texture(const std::string& name) {
+    const TexInfo& tex_info(const std::string& name) {
         auto it = textures.find(name);
         if (it == textures.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no texture named '" + name + "'");
         return it->second;
+    }
+    // value of a constant texture; for an image-backed one its TextureT::average_color
+    V3 texture(const std::string& name) {
+        const TexInfo& t = tex_info(name);
+        return t.constant ? t.value : tex_average(t.node);
+    }
+
+    // TextureT::average_color (scalar.rs:37-39, image_tex.rs:41-44, binary_op.rs:58-60, srgb_tex.rs:30-32,
+    // input_modifier.rs:88-90)
+    V3 tex_average(uint32_t node) {
+        const spt_texture& t = hs.textures[node];
+        switch (t.type) {
+        case SPT_TEX_SCALAR: return {t.value[0], t.value[1], t.value[2]};
+        case SPT_TEX_IMAGE: {
+            const spt_image& im = hs.images[t.image];
+            uint32_t px = hs.texels[hs.image_levels[im.first_level + im.n_levels - 1].first_texel];
+            return {(float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f};
+        }
+        case SPT_TEX_ADD: return tex_average(t.a) + tex_average(t.b);
+        case SPT_TEX_SUB: return tex_average(t.a) - tex_average(t.b);
+        case SPT_TEX_MUL: return tex_average(t.a) * tex_average(t.b);
+        case SPT_TEX_DIV: { V3 a = tex_average(t.a), b = tex_average(t.b); return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+        case SPT_TEX_SRGB: { V3 a = tex_average(t.a); return {srgb_to_linear(a.x), srgb_to_linear(a.y), srgb_to_linear(a.z)}; }
+        default: return tex_average(t.a);
+        }
+    }
+
+    // ImageTex::new + generate_mipmap (src/texture/image_tex.rs:12-15,66-100): box-filtered u8 pyramid,
+    // odd sizes round up and clamp the second tap, the mean is truncated (`as u8`)
+    uint32_t add_image(const std::string& file) {
+        auto it = image_ids.find(file);
+        if (it != image_ids.end()) return it->second;
+        uint32_t w = 0, h = 0;
+        std::vector<uint32_t> lvl;
+        read_png_rgba8(file, &w, &h, &lvl);
+        spt_image im;
+        im.first_level = (uint32_t)hs.image_levels.size();
+        im.n_levels = 0;
+        while (true) {
+            if (hs.texels.size() + lvl.size() > 0xffffffffull) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "image textures exceed 2^32 texels");
+            spt_image_level L;
+            L.width = w; L.height = h; L.first_texel = (uint32_t)hs.texels.size(); L.pad = 0;
+            hs.image_levels.push_back(L);
+            hs.texels.insert(hs.texels.end(), lvl.begin(), lvl.end());
+            ++im.n_levels;
+            if (w <= 1 && h <= 1) break;
+            uint32_t nw = (w + 1) >> 1, nh = (h + 1) >> 1;
+            std::vector<uint32_t> next((size_t)nw * nh);
+            for (uint32_t i = 0; i < nw; ++i)
+                for (uint32_t j = 0; j < nh; ++j) {
+                    uint32_t x0 = 2 * i, x1 = std::min(2 * i + 1, w - 1), y0 = 2 * j, y1 = std::min(2 * j + 1, h - 1);
+                    uint32_t p0 = lvl[(size_t)y0 * w + x0], p1 = lvl[(size_t)y1 * w + x0], p2 = lvl[(size_t)y0 * w + x1], p3 = lvl[(size_t)y1 * w + x1];
+                    uint32_t out = 0;
+                    for (int c = 0; c < 4; ++c) {
+                        float sum = (((float)((p0 >> (8 * c)) & 255u) + (float)((p1 >> (8 * c)) & 255u)) + (float)((p2 >> (8 * c)) & 255u)) + (float)((p3 >> (8 * c)) & 255u);
+                        out |= ((uint32_t)(sum * 0.25f) & 255u) << (8 * c);
+                    }
+                    next[(size_t)j * nw + i] = out;
+                }
+            lvl.swap(next);
+            w = nw; h = nh;
+        }
+        hs.images.push_back(im);
+        image_ids[file] = (uint32_t)hs.images.size() - 1;
+        return (uint32_t)hs.images.size() - 1;
+    }
+
+    uint32_t add_tex_node(uint32_t type, uint32_t a = 0, uint32_t b = 0) {
+        spt_texture t;
+        std::memset(&t, 0, sizeof t);
+        t.type = type; t.a = a; t.b = b;
+        t.mode = -1; t.wrap = -1;
+        t.tiling[0] = t.tiling[1] = t.tiling[2] = 1.0f;
+        hs.textures.push_back(t);
+        return (uint32_t)hs.textures.size() - 1;
     }
 
     // camera::create_camera_from_params + PerspectiveCamera::new (src/camera/perspective.rs:15-37)
@@ -368,32 +454,87 @@ struct SceneBuilder {
         p.check_unused();
     }
 
-    // texture::create_texture_from_params (src/texture/mod.rs:210-243), scalar-valued subset
+    // texture::create_texture_from_params (src/texture/mod.rs:210-243)
     void load_texture(Params& p) {
         p.set_name("texture");
         std::string ty = p.get_str("type"), name = p.get_str("name");
         p.set_name("texture-" + ty + "-" + name);
-        V3 val;
+        TexInfo info;
+        info.constant = true;
+        info.value = {0, 0, 0};
         if (ty == "scalar") {
-            val = p.get_float3("value");
+            info.value = p.get_float3("value");
+            info.node = add_tex_node(SPT_TEX_SCALAR);
+            hs.textures[info.node].value[0] = info.value.x;
+            hs.textures[info.node].value[1] = info.value.y;
+            hs.textures[info.node].value[2] = info.value.z;
         } else if (ty == "add" || ty == "sub" || ty == "mul" || ty == "div") {
-            V3 a = texture(p.get_str("t1")), b = texture(p.get_str("t2"));
-            if (ty == "add") val = a + b;
-            else if (ty == "sub") val = a - b;
-            else if (ty == "mul") val = a * b;
-            else val = {a.x / b.x, a.y / b.y, a.z / b.z};
+            const TexInfo ta = tex_info(p.get_str("t1")), tb = tex_info(p.get_str("t2"));
+            V3 a = ta.value, b = tb.value;
+            uint32_t op;
+            if (ty == "add") { info.value = a + b; op = SPT_TEX_ADD; }
+            else if (ty == "sub") { info.value = a - b; op = SPT_TEX_SUB; }
+            else if (ty == "mul") { info.value = a * b; op = SPT_TEX_MUL; }
+            else { info.value = {a.x / b.x, a.y / b.y, a.z / b.z}; op = SPT_TEX_DIV; }
+            info.constant = ta.constant && tb.constant;
+            info.node = add_tex_node(op, ta.node, tb.node);
         } else if (ty == "image") {
-            throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": image textures are outside the hot-path scope (SURVEY 8f-2)");
+            // InputParams::get_image (src/core/loader.rs:366-371): relative to the scene file
+            std::string file = with_file_name(path, p.get_str("image_file"));
+            uint32_t im;
+            try {
+                im = add_image(file);
+            } catch (const HostError& e) {
+                throw HostError(e.code, p.name() + " - " + e.msg);
+            }
+            info.constant = false;
+            info.node = add_tex_node(SPT_TEX_IMAGE);
+            hs.textures[info.node].image = im;
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
         }
-        if (p.get_bool_or("is_srgb", false)) val = {srgb_to_linear(val.x), srgb_to_linear(val.y), srgb_to_linear(val.z)};
-        // remaining keys (tiling/offset/mode/wrap) wrap the texture in a TexInputModifier,
-        // which is the identity for a constant texture
-        for (const char* k : {"tiling", "offset", "mode", "wrap"})
-            if (p.contains(k)) p.mark(k);
+        if (p.get_bool_or("is_srgb", false)) {
+            info.value = {srgb_to_linear(info.value.x), srgb_to_linear(info.value.y), srgb_to_linear(info.value.z)};
+            info.node = add_tex_node(SPT_TEX_SRGB, info.node);
+        }
+        // any key left (tiling / offset / mode / wrap, or a typo) wraps the texture in a TexInputModifier
+        // (mod.rs:235-237, input_modifier.rs:52-71); it is the identity on a constant texture
+        if (p.num_unused() > 0) {
+            int32_t mode = -1, wrap = -1;
+            if (p.contains("mode")) {
+                std::string m = p.get_str("mode");
+                if (m == "texcoords") mode = SPT_TEXMODE_TEXCOORDS;
+                else if (m == "position") mode = SPT_TEXMODE_POSITION;
+                else if (m == "normal") mode = SPT_TEXMODE_NORMAL;
+                else if (m == "tangent") mode = SPT_TEXMODE_TANGENT;
+                else if (m == "bitangent") mode = SPT_TEXMODE_BITANGENT;
+                else throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + " - Unknown texture input mode '" + m + "'");
+            }
+            if (p.contains("wrap")) {
+                std::string m = p.get_str("wrap");
+                if (m == "repeat") wrap = SPT_TEXWRAP_REPEAT;
+                else if (m == "mirror_repeat") wrap = SPT_TEXWRAP_MIRROR_REPEAT;
+                else if (m == "clamp") wrap = SPT_TEXWRAP_CLAMP;
+                else if (m == "mirror_clamp") wrap = SPT_TEXWRAP_MIRROR_CLAMP;
+                else throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + " - Unknown texture input wrap mode '" + m + "'");
+            }
+            V3 tiling, offset;
+            if (mode < 0 || mode == SPT_TEXMODE_TEXCOORDS) {
+                std::array<float, 2> t2 = p.get_float2_or("tiling", {1.0f, 1.0f}), o2 = p.get_float2_or("offset", {0.0f, 0.0f});
+                tiling = {t2[0], t2[1], 1.0f};
+                offset = {o2[0], o2[1], 0.0f};
+            } else {
+                tiling = p.get_float3_or("tiling", {1, 1, 1});
+                offset = p.get_float3_or("offset", {0, 0, 0});
+            }
+            info.node = add_tex_node(SPT_TEX_MODIFIER, info.node);
+            spt_texture& t = hs.textures[info.node];
+            t.mode = mode; t.wrap = wrap;
+            t.tiling[0] = tiling.x; t.tiling[1] = tiling.y; t.tiling[2] = tiling.z;
+            t.offset[0] = offset.x; t.offset[1] = offset.y; t.offset[2] = offset.z;
+        }
         if (textures.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated texture name '" + name + "'");
-        textures[name] = val;
+        textures[name] = info;
         p.check_unused();
     }
 
@@ -481,6 +622,35 @@ struct SceneBuilder {
             throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)");
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
+        }
+        // a parameter backed by an image: keep the recipe, the device evaluates bxdf_context at every hit
+        {
+            spt_material_recipe r;
+            std::memset(&r, 0, sizeof r);
+            bool textured = false;
+            auto slot = [&](int i, const char* key) {
+                const TexInfo& t = tex_info(p.get_str(key));
+                r.tex[i] = t.node;
+                textured = textured || !t.constant;
+            };
+            auto rough_slots = [&]() {
+                if (p.contains("roughness")) { slot(2, "roughness"); r.tex[3] = r.tex[2]; }
+                else { slot(2, "roughness_x"); slot(3, "roughness_y"); }
+            };
+            r.rough_chan = SPT_CHAN_R;
+            r.metal_chan = SPT_CHAN_R;
+            r.ior = m.ior;
+            if (ty == "lambert") { r.type = SPT_MAT_LAMBERT; slot(0, "albedo"); }
+            else if (ty == "conductor") { r.type = SPT_MAT_CONDUCTOR; slot(0, "ior"); slot(1, "ior_k"); rough_slots(); }
+            else if (ty == "dielectric") { r.type = SPT_MAT_DIELECTRIC; rough_slots(); }
+            else if (ty == "plastic") { r.type = SPT_MAT_PLASTIC; slot(0, "albedo"); rough_slots(); }
+            else if (ty == "pbr_metallic") { r.type = SPT_MAT_PBR_METALLIC; slot(0, "base_color"); slot(1, "metallic"); rough_slots(); }
+            else if (ty == "pbr_specular") { r.type = SPT_MAT_PBR_SPECULAR; slot(0, "diffuse"); slot(1, "specular"); rough_slots(); }
+            if (textured) {
+                hs.material_recipes.push_back(r);
+                m.recipe = (uint32_t)hs.material_recipes.size();
+                any_textured = true;
+            }
         }
         if (materials.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated material name '" + name + "'");
         materials[name] = (uint32_t)hs.materials.size();
@@ -603,13 +773,16 @@ struct SceneBuilder {
         std::string mat = p.get_str("material");
         auto mi = materials.find(mat);
         if (mi == materials.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no material named '" + mat + "'");
-        for (const char* k : {"normal_map", "emissive_map"})
-            if (p.contains(k)) {
-                (void)texture(p.get_str(k));
-                throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": '" + k + "' is outside the hot-path scope (SURVEY 8f-2)");
-            }
+        uint32_t normal_map = 0, emissive_map = 0;   // texture node + 1
+        if (p.contains("normal_map")) normal_map = tex_info(p.get_str("normal_map")).node + 1;
         if (p.contains("displacement_map")) (void)texture(p.get_str("displacement_map"));  // loaded, unused (surface.rs:17)
         V3 em = p.get_float3_or("emissive", {0, 0, 0});
+        V3 em_avg = em;                              // Surface::average_emissive (surface.rs:57-63)
+        if (p.contains("emissive_map")) {
+            std::string en = p.get_str("emissive_map");
+            emissive_map = tex_info(en).node + 1;
+            em_avg = em * texture(en);
+        }
         bool ds = p.get_bool_or("double_sided", false);
         int32_t med = -1;
         if (p.contains("inside_medium")) {
@@ -619,7 +792,12 @@ struct SceneBuilder {
             med = (int32_t)it->second;
         }
         if (surfaces.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated surface name '" + name + "'");
-        surfaces[name] = add_surface(mi->second, em, ds, med);
+        uint32_t si = add_surface(mi->second, em, ds, med);
+        hs.surfaces[si].normal_map = normal_map;
+        hs.surfaces[si].emissive_map = emissive_map;
+        avg_emissive[si] = em_avg;
+        if (normal_map || emissive_map) any_textured = true;
+        surfaces[name] = si;
         p.check_unused();
     }
 
@@ -937,6 +1115,11 @@ void HostScene::finalize_desc() {
     desc.env.alias.props = env_props.data();
     desc.env.alias.u = env_u.data();
     desc.env.alias.k = env_k.data();
+    desc.n_textures = (uint32_t)textures.size(); desc.textures = textures.data();
+    desc.n_images = (uint32_t)images.size(); desc.images = images.data();
+    desc.n_image_levels = (uint32_t)image_levels.size(); desc.image_levels = image_levels.data();
+    desc.n_texels = (uint32_t)texels.size(); desc.texels = texels.data();
+    desc.n_material_recipes = (uint32_t)material_recipes.size(); desc.material_recipes = material_recipes.data();
 }
 
 // loader::load_scene (src/loader/json.rs:53-199): fixed section order

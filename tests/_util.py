@@ -84,6 +84,9 @@ def oracle_lib():
         lib.oracle_rng_state.restype = C.c_uint64
         lib.oracle_r2_offsets.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.oracle_r2_offsets.restype = None
+        lib.oracle_tex_eval.argtypes = [C.POINTER(spt.SceneDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.oracle_calc_differential.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_calc_differential.restype = None
         _oracle = lib
     return _oracle
 
@@ -102,6 +105,24 @@ def oracle_render(scene, renderer, width, height, camera=None, flags=0, threads=
     rc = lib.oracle_render(C.byref(desc), C.byref(cam), C.byref(p), flags, threads, out.ctypes.data, C.byref(st))
     assert rc == 0
     return out, st
+
+
+def oracle_tex_eval(scene, node, uv, duvdx=(0.0, 0.0), duvdy=(0.0, 0.0), position=None, normal=None, flags=0):
+    """RGBA of texture `node` at texcoords `uv` (n, 2); the other TextureInput fields default to zero."""
+    uv = np.atleast_2d(np.asarray(uv, dtype=np.float32))
+    n = uv.shape[0]
+    inp = np.zeros((n, 18), dtype=np.float32)
+    if position is not None:
+        inp[:, 0:3] = position
+    if normal is not None:
+        inp[:, 3:6] = normal
+    inp[:, 12:14] = uv
+    inp[:, 14:16] = duvdx
+    inp[:, 16:18] = duvdy
+    out = np.zeros((n, 4), dtype=np.float32)
+    desc = scene.desc
+    assert oracle_lib().oracle_tex_eval(C.byref(desc), flags, node, n, inp.ctypes.data, out.ctypes.data) == 0
+    return out
 
 
 def oracle_trace_closest(scene, rays, flags=0):

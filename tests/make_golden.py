@@ -18,6 +18,7 @@ CASES = [  # name, scene, camera, sampler, spp, (w, h), seed
     ("film_t_power_is", "t_power_is.json", "top", "jittered", 16, (64, 48), 1),
     ("film_t_medium", "t_medium.json", None, "random", 16, (64, 48), 1),
     ("film_t_plastic", "t_plastic.json", None, "random", 16, (64, 48), 1),
+    ("film_t_textured", "t_textured.json", None, "recurrence", 16, (64, 48), 1),
 ]
 
 

@@ -71,6 +71,26 @@ def test_round_floor_match_rust_semantics():
     assert np.array_equal(_eval(8, y), np.floor(y))
 
 
+def test_pow_log2_trunc_fract_for_textures():
+    # sRGB decode: pow(x, 2.4) on ((s + 0.055) / 1.055) for s in (0.04045, 1]
+    x = np.linspace(0.09, 1.0, 200_001, dtype=np.float32)
+    e = np.full_like(x, 2.4)
+    ref = np.power(x.astype(np.float64), np.float64(np.float32(2.4)))
+    assert (np.abs(_eval(13, x, e) - ref) / ref).max() < 1.2e-6
+    assert _eval(13, np.array([0.0, 0.0, 2.0], np.float32), np.array([2.4, 0.0, 0.0], np.float32)).tolist() == [0.0, 1.0, 1.0]
+    # mip level: log2 over footprints 1e-3 .. 1e4 texels
+    y = np.geomspace(1e-3, 1e4, 100_001).astype(np.float32)
+    assert np.abs(_eval(14, y) - np.log2(y.astype(np.float64))).max() < 2e-6
+    # f32::trunc / fract (wrap modes), NaN and huge values pass through floor / round untouched
+    z = np.array([1.75, -1.75, 0.25, -0.25, 3.0, -0.0, 8388608.0, 1e30, -1e30], np.float32)
+    assert np.array_equal(_eval(15, z), np.trunc(z))
+    assert np.array_equal(_eval(16, z), z - np.trunc(z))
+    assert np.isnan(_eval(16, np.array([np.inf], np.float32))[0])
+    big = np.array([1e30, -1e30, np.inf, -np.inf, 16777216.0], np.float32)
+    assert np.array_equal(_eval(8, big), big) and np.array_equal(_eval(7, big), big)
+    assert np.isnan(_eval(8, np.array([np.nan], np.float32))[0]) and np.isnan(_eval(7, np.array([np.nan], np.float32))[0])
+
+
 def test_rng_is_pcg32_xsh_rr_and_uniform():
     lib = _util.oracle_lib()
     # independent re-implementation of the stream definition

@@ -37,6 +37,13 @@ def test_elementary_functions_bit_identical():
     v[:6] = [0.5, 1.5, -0.5, 2.5, 0.49999997, -2.5]
     _same(7, v)
     _same(8, v)
+    # image-texture helpers: pow (sRGB decode), log2 (mip level), trunc / fract (wrap), total floor / round
+    base = np.concatenate([np.linspace(0.0, 1.2, 200_001), [0.0, 1.0]]).astype(np.float32)
+    _same(13, base, np.full_like(base, 2.4))
+    _same(14, np.geomspace(1e-4, 1e5, 100_001).astype(np.float32))
+    w = np.concatenate([rng.uniform(-50, 50, 100_000), [np.nan, np.inf, -np.inf, 1e30, -1e30, -0.0, 8388608.0]]).astype(np.float32)
+    for fn in (15, 16, 7, 8):
+        _same(fn, w)
 
 
 def test_ieee_sqrt_div_min_max_bit_identical():

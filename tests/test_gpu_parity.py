@@ -26,7 +26,7 @@ def _scene(spt, name):
     return spt.load_scene(os.path.join(_util.SCENES, name))
 
 
-@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json"])
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json"])
 def test_trace_closest_and_any_bit_exact(spt, scene_name):
     sc = _scene(spt, scene_name)
     rays = _util.random_rays(sc, 200_000, seed=11)
@@ -89,6 +89,8 @@ def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
     ("t_power_is.json", "main", "recurrence"),   # power_is alias-table sampler, colour environment, group aggregate
     ("t_medium.json", None, "random"),           # homogeneous media (HG g=0.3 and isotropic), pseudo boundary, area light
     ("t_plastic.json", None, "random"),          # plastic (rough/smooth/aniso), pbr_metallic, pbr_specular
+    ("t_textured.json", None, "random"),         # image textures: mips + trilinear (camera-ray differentials), wrap / tiling /
+    ("t_textured.json", None, "recurrence"),     #   mode, sRGB, binary ops, normal + emissive maps, per-hit material recipes
 ])
 def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     sc = _scene(spt, scene_name)
@@ -97,10 +99,15 @@ def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     w, h = 160, 120
     ref, _ = _util.oracle_render(sc, r, w, h, camera=camera, flags=_util.ORACLE_DEVICE)
     got = r.render_shard(sc, spt.OutputConfig(w, h, None, camera), samples_per_pass=6)
-    assert np.isfinite(ref).all()
-    l1 = float(np.abs(got - ref).mean())
+    # texcoords at a sphere pole can be NaN in the reference too (acos of a normal.y a hair above 1,
+    # sphere.rs:138-145): such pixels must be NaN on both sides, everything else bit-exact
+    nan = np.isnan(ref)
+    assert nan.mean() < 1e-3 and np.array_equal(nan, np.isnan(got))
+    if scene_name != "t_textured.json":
+        assert not nan.any()
+    l1 = float(np.abs(got - ref)[~nan].mean())
     assert l1 < L1_TOL, l1
-    mism = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    mism = int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum())
     assert mism == 0, "radiance not bit-exact: %d words differ, L1 %.3g" % (mism, l1)
 
 
