@@ -66,6 +66,7 @@ struct RenderCtx {
     uint32_t pass_samples;    // samples per pixel in this pass
     PathQueue qa, qb;         // qa: paths with a hit record (input of shade); qb: paths to extend
     HitQueue hits;
+    HitQueue hits_next;       // fused bounces only: hit records of the NEXT bounce (ping-pong with `hits`)
     ShadowQueue shadow;
     uint32_t* counts;         // [bounce][3 queues][kShards] lengths, one 128-B line each (see q_count)
     uint32_t shard_cap;       // entries per queue shard
@@ -280,9 +281,15 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // kFeat 0 = kSimple, 1 = the general path.
 // kFeat 2 (textured): some material parameter, normal map or emissive map is an image texture; adds
 // texcoords, the camera ray differentials of bounce 0 and the per-hit material evaluation.
-template <int kFeat, bool kFirst>
+// kFused (scenes whose traversal geometry is LDS-resident): the shadow ray and the extension ray are traced
+// right here instead of going through the shadow / extend queues and kernels.  The shade queue is dense,
+// so the waves are as full for the two traversals as they would be in k_shadow / k_extend, and the
+// 48-B shadow + 72-B path records (written once, read once: 240 B per path vertex) never touch HBM.
+// Next-bounce vertices go to (qb, hits_next); the host swaps the two buffer pairs every bounce.
+template <int kFeat, bool kFirst, bool kFused = false>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     constexpr bool kSimple = kFeat == 0, kTex = kFeat == 2;
+    if (kFused) stage_geometry<true>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
     uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
@@ -511,6 +518,36 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     }
                 }
             }
+        }
+        if (kFused) {
+            // the two queue counters still count the segments (spt_render_stats); the slots are not used
+            const PendingPush ps = wave_push_issue(want_shadow, shadow_count);
+            const PendingPush pe = wave_push_issue(want_ext, ext_count);
+            if (want_shadow && !trace_any<true>(sc, shadow_ray, shadow_tmax)) rad_add(rc, slot, contrib);   // k_shadow
+            bool keep = false;                                                                               // k_extend
+            DHit nh;
+            nh.inst = -1; nh.t = SPT_F32_MAX; nh.prim = -1; nh.v = 0.0f; nh.w = 0.0f;
+            if (want_ext && bounce + 1u < rc.max_depth) {   // the host launches no k_extend after the last bounce either
+                nh = trace_closest<true>(sc, next_ray, SPT_F32_MAX);
+                if (nh.inst >= 0 || medium >= 0) {
+                    keep = true;
+                } else if (!kSimple && sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
+                    f3 env;
+                    float env_pdf;
+                    env_strength_pdf(sc, next_ray.d, &env, &env_pdf);
+                    float weight = power_heuristic(next_pdf, pdf_env_light(sc) * env_pdf);
+                    rad_add(rc, slot, (thr * env) * weight);
+                }
+            }
+            (void)wave_push_finish(ps);
+            (void)wave_push_finish(pe);
+            const uint32_t ns = qbase + wave_push(keep, q_count(rc.counts, bounce + 1, Q_HIT, shard));
+            if (keep) {
+                store_path(rc.qb, ns, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
+                rc.hits_next.t_v_w_prim[ns] = make_float4(nh.t, nh.v, nh.w, __int_as_float(nh.prim));
+                rc.hits_next.inst[ns] = nh.inst;
+            }
+            continue;
         }
         // both reservations in flight together: one atomic round trip per iteration instead of two
         const PendingPush ps = wave_push_issue(want_shadow, shadow_count);

@@ -285,7 +285,7 @@ struct spt_scene {
     bool lds_geo = false;   // traversal geometry small enough to live in LDS (k_*<true>)
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
-    DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, sh[3], counts, rad, film, first_slot, out;
+    DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, out;
     DeviceBuffer trace_in, trace_out;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
@@ -753,6 +753,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         sc->qb[4].ensure(cap * 8);
         sc->hit_f4.ensure(cap * 16);
         sc->hit_inst.ensure(cap * 4);
+        const bool fused = sc->lds_geo && std::getenv("SPT_NO_FUSED") == nullptr;   // see k_shade<.., kFused>
+        if (fused) {
+            sc->hit_f4_next.ensure(cap * 16);
+            sc->hit_inst_next.ensure(cap * 4);
+        }
         for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
         const size_t counts_words = (size_t)(p.max_depth + 1) * Q_KINDS * kShards * 32;
         const size_t counts_bytes = counts_words * sizeof(uint32_t);
@@ -778,6 +783,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         rc.qa = PathQueue{sc->qa[0].as<float4>(), sc->qa[1].as<float4>(), sc->qa[2].as<float4>(), sc->qa[3].as<float4>(), sc->qa[4].as<uint2>()};
         rc.qb = PathQueue{sc->qb[0].as<float4>(), sc->qb[1].as<float4>(), sc->qb[2].as<float4>(), sc->qb[3].as<float4>(), sc->qb[4].as<uint2>()};
         rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
+        rc.hits_next = HitQueue{sc->hit_f4_next.as<float4>(), sc->hit_inst_next.as<int32_t>()};
         rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
         rc.counts = sc->counts.as<uint32_t>();
         rc.shard_cap = (uint32_t)shard_cap64;
@@ -851,6 +857,19 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             end();
             for (uint32_t b = 0; b < p.max_depth; ++b) {
                 begin(SPT_K_SHADE);
+                if (fused) {
+                    // shade + shadow + extend of this bounce in one kernel; vertices of bounce b live in
+                    // (qa, hits) for even b and in (qb, hits_next) for odd b
+                    RenderCtx rb = rc;
+                    if (b & 1u) { std::swap(rb.qa, rb.qb); std::swap(rb.hits, rb.hits_next); }
+#define SPT_LAUNCH_FUSED(FEAT)                                                                                                       \
+    if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);          \
+    else hipLaunchKernelGGL((k_shade<FEAT, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                    if (sc->simple) { SPT_LAUNCH_FUSED(0) } else if (!sc->textured) { SPT_LAUNCH_FUSED(1) } else { SPT_LAUNCH_FUSED(2) }
+#undef SPT_LAUNCH_FUSED
+                    end();
+                    continue;
+                }
                 if (sc->simple) {
                     if (b == 0) hipLaunchKernelGGL((k_shade<0, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
                     else hipLaunchKernelGGL((k_shade<0, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
