@@ -176,9 +176,14 @@ def main():
         # ALGORITHMIC bytes each kernel class moves per step (DESIGN.md "Kernels and rooflines"):
         # queue records written/read once + radiance-slot / film read-modify-writes; scene geometry of
         # this workload (< 2 KB) is LDS-resident and counted as 0 ("count it once").
+        # fused bounces (LDS-resident scenes): shade traces its own shadow / extension rays, so the shadow and
+        # path-to-extend records do not exist; it reads the vertices, writes the next bounce's vertices and
+        # read-modify-writes one radiance slot per (unoccluded) shadow ray
+        fused = int(kernel_launches[2]) == 0 and int(kernel_launches[3]) == 0
         alg = {
             "primary": hits0 * (S_PATH0 + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
-            "shade": hits0 * (S_PATH0 + S_HIT) + (verts - hits0) * (S_PATH + S_HIT) + seg_s * S_SHADOW + ext * S_PATH,
+            "shade": (hits0 * (S_PATH0 + S_HIT) + 2 * (verts - hits0) * (S_PATH + S_HIT) + seg_s * 2 * S_RAD) if fused else
+                     hits0 * (S_PATH0 + S_HIT) + (verts - hits0) * (S_PATH + S_HIT) + seg_s * S_SHADOW + ext * S_PATH,
             "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
             "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
             "resolve": hits0 * S_RAD + passes * n_pix * 2 * S_RAD,

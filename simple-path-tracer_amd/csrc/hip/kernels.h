@@ -286,6 +286,7 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // so the waves are as full for the two traversals as they would be in k_shadow / k_extend, and the
 // 48-B shadow + 72-B path records (written once, read once: 240 B per path vertex) never touch HBM.
 // Next-bounce vertices go to (qb, hits_next); the host swaps the two buffer pairs every bounce.
+// (139 VGPRs for kFeat 0 = 3 waves / SIMD; forcing 128 with a launch bound spills 12 and measured the same.)
 template <int kFeat, bool kFirst, bool kFused = false>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     constexpr bool kSimple = kFeat == 0, kTex = kFeat == 2;

@@ -94,6 +94,141 @@ uint32_t bvh_depth(const spt_bvh_node* nodes, uint32_t n_nodes, uint32_t root, u
     return depth;
 }
 
+// ---- device-side BLAS ---------------------------------------------------------------------------
+// The ABI hands over the caller's trees (the reference side would flatten ITS BvhAccel, whose builder bins
+// a primitive by (centroid - its OWN bbox min) / bucket length, src/primitive/bvh.rs:52-57, i.e. by size
+// rather than position; libspt_host.so builds a proper binned-SAH tree but always splits down to <= 4).
+// A closest / any hit does not depend on the tree, only on the set of triangles, so the library does not
+// rely on the caller's tree quality: it builds its own binned-SAH tree per mesh (32 bins, 3 axes, SAH
+// leaf termination, leaves of <= 4) over the same triangles.  Node boxes are padded outward (2^-16 of
+// the extent + 2^-20 of the magnitude) so that every ray the triangle test accepts also passes the boxes
+// above that triangle.  What can differ from a walk of the caller's tree are only the triangle test's own
+// false positives for rays grazing a triangle's plane outside its padded box (~1e-7 per ray; none in any
+// committed parity case); SPT_REFERENCE_BVH=1 walks the ABI trees instead, and the GPU parity suite is
+// green (bit-identical films) in both modes.  Triangles are re-ordered into leaf order in the traversal
+// blob; each carries its ABI index in the pad lane of its first vertex (tie-rule key, tri_attr index).
+// Measured against libspt_host's trees: cfg2 38.4 -> 39.3 Gsamples/s, cfg5 761 -> 777 Msamples/s.
+struct SahTri {
+    float lo[3], hi[3], c[3];
+    uint32_t id;
+};
+void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_count, std::vector<spt_bvh_node>& nodes,
+                    std::vector<uint32_t>& order /* slot (absolute) -> ABI triangle index, filled for this mesh's range */) {
+    std::vector<SahTri> t(tri_count);
+    for (uint32_t i = 0; i < tri_count; ++i) {
+        const spt_tri_pos& p = tris[tri_first + i];
+        for (int k = 0; k < 3; ++k) {
+            t[i].lo[k] = std::min(p.p0[k], std::min(p.p1[k], p.p2[k]));
+            t[i].hi[k] = std::max(p.p0[k], std::max(p.p1[k], p.p2[k]));
+            t[i].c[k] = 0.5f * (t[i].lo[k] + t[i].hi[k]);
+        }
+        t[i].id = tri_first + i;
+    }
+    constexpr int kBins = 32;
+    constexpr uint32_t kMaxLeaf = 4;
+    constexpr float kTraversalCost = 1.2f;   // one wide-node visit (two slab tests) relative to one triangle test
+    auto half_area = [](const float* lo, const float* hi) {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Task { uint32_t begin, end, node, depth; };
+    std::vector<Task> st;
+    nodes.push_back(spt_bvh_node{});
+    st.push_back(Task{0u, tri_count, (uint32_t)nodes.size() - 1u, 0u});
+    while (!st.empty()) {
+        const Task tk = st.back();
+        st.pop_back();
+        const uint32_t n = tk.end - tk.begin;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = tk.begin; i < tk.end; ++i)
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], t[i].lo[k]); hi[k] = std::max(hi[k], t[i].hi[k]);
+                clo[k] = std::min(clo[k], t[i].c[k]); chi[k] = std::max(chi[k], t[i].c[k]);
+            }
+        spt_bvh_node nd;
+        for (int k = 0; k < 3; ++k) {
+            const float pad = (hi[k] - lo[k]) * 1.52587890625e-5f + std::max(std::fabs(lo[k]), std::fabs(hi[k])) * 9.5367431640625e-7f + 1e-30f;
+            nd.bmin[k] = lo[k] - pad;
+            nd.bmax[k] = hi[k] + pad;
+        }
+        auto make_leaf = [&]() {
+            nd.a = tri_first + tk.begin;
+            nd.b = SPT_LEAF_FLAG | n;
+            nodes[tk.node] = nd;
+        };
+        if (n == 1) { make_leaf(); continue; }
+        // best binned split over the three axes
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = 0;
+        for (int k = 0; k < 3; ++k) {
+            const float ext = chi[k] - clo[k];
+            if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
+            const float scale = (float)kBins / ext;
+            uint32_t cnt[kBins] = {};
+            float blo[kBins][3], bhi[kBins][3];
+            for (int b = 0; b < kBins; ++b)
+                for (int j = 0; j < 3; ++j) { blo[b][j] = INFINITY; bhi[b][j] = -INFINITY; }
+            for (uint32_t i = tk.begin; i < tk.end; ++i) {
+                int b = std::min(kBins - 1, std::max(0, (int)((t[i].c[k] - clo[k]) * scale)));
+                ++cnt[b];
+                for (int j = 0; j < 3; ++j) { blo[b][j] = std::min(blo[b][j], t[i].lo[j]); bhi[b][j] = std::max(bhi[b][j], t[i].hi[j]); }
+            }
+            float right_area[kBins];
+            uint32_t right_cnt[kBins];
+            {
+                float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t rc = 0;
+                for (int b = kBins - 1; b >= 1; --b) {
+                    for (int j = 0; j < 3; ++j) { rl[j] = std::min(rl[j], blo[b][j]); rh[j] = std::max(rh[j], bhi[b][j]); }
+                    rc += cnt[b];
+                    right_area[b] = rc ? half_area(rl, rh) : 0.0f;
+                    right_cnt[b] = rc;
+                }
+            }
+            float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t lc = 0;
+            for (int b = 1; b < kBins; ++b) {   // split between bin b-1 and b
+                for (int j = 0; j < 3; ++j) { ll[j] = std::min(ll[j], blo[b - 1][j]); lh[j] = std::max(lh[j], bhi[b - 1][j]); }
+                lc += cnt[b - 1];
+                if (lc == 0 || right_cnt[b] == 0) continue;
+                const float cost = half_area(ll, lh) * (float)lc + right_area[b] * (float)right_cnt[b];
+                if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = b; }
+            }
+        }
+        const float node_area = half_area(lo, hi);
+        uint32_t mid;
+        if (best_axis >= 0 && tk.depth < 56u) {
+            const float split_cost = kTraversalCost + (node_area > 0.0f ? best_cost / node_area : (float)n);
+            if (n <= kMaxLeaf && (float)n <= split_cost) { make_leaf(); continue; }
+            const float ext = chi[best_axis] - clo[best_axis];
+            const float scale = (float)kBins / ext;
+            auto it = std::partition(t.begin() + tk.begin, t.begin() + tk.end, [&](const SahTri& x) {
+                int b = std::min(kBins - 1, std::max(0, (int)((x.c[best_axis] - clo[best_axis]) * scale)));
+                return b < best_bin;
+            });
+            mid = (uint32_t)(it - t.begin());
+        } else {
+            // all centroids coincide (or the tree got too deep): leaf if it fits, else split the range in half
+            if (n <= kMaxLeaf) { make_leaf(); continue; }
+            mid = tk.begin + n / 2;
+            if (best_axis >= 0) {
+                const int ax = best_axis;
+                std::nth_element(t.begin() + tk.begin, t.begin() + mid, t.begin() + tk.end, [&](const SahTri& x, const SahTri& y) { return x.c[ax] < y.c[ax]; });
+            }
+        }
+        if (mid == tk.begin || mid == tk.end) mid = tk.begin + n / 2;
+        nd.a = (uint32_t)nodes.size();
+        nd.b = nd.a + 1u;
+        nodes[tk.node] = nd;
+        nodes.push_back(spt_bvh_node{});
+        nodes.push_back(spt_bvh_node{});
+        st.push_back(Task{mid, tk.end, nd.b, tk.depth + 1u});
+        st.push_back(Task{tk.begin, mid, nd.a, tk.depth + 1u});
+    }
+    for (uint32_t i = 0; i < tri_count; ++i) order[tri_first + i] = t[i].id;
+}
+
 // Repack one 32-byte-node tree into 64-byte wide nodes (see trace.h).  Returns the index of the
 // super-root inside `wide` (in wide-node units).  The first `bfs_nodes` wide nodes are numbered
 // breadth-first (they are the ones staged into LDS for large scenes), the subtrees below them
@@ -462,8 +597,10 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             blas_depth = std::max(blas_depth, bvh_depth(s.blas_nodes, s.n_blas_nodes, s.meshes[i].root, s.n_tris, "blas"));
         }
         // near-first traversal pushes at most one (far) child per 2-wide level (4-wide trees: see build_n4)
+        const bool own_bvh = std::getenv("SPT_REFERENCE_BVH") == nullptr;   // see build_sah_blas
         uint32_t cap = tlas_depth + blas_depth + 2;
-        if (cap > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (48 levels)");
+        if (!own_bvh && cap > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (48 levels)");
+        if (tlas_depth + 2 > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "TLAS deeper than the traversal stack (48 levels)");
         sc->tlas.upload(s.tlas_nodes, s.n_tlas_nodes);
         sc->blas.upload(s.blas_nodes, s.n_blas_nodes);
         sc->tri_pos.upload(s.tri_pos, s.n_tris);
@@ -533,20 +670,40 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = s.tlas_nodes[0].bmin[k]; d.tlas_hi[k] = s.tlas_nodes[0].bmax[k]; }
             }
             // BLAS: 2-wide full-precision nodes when the whole scene fits LDS, compressed 4-wide nodes otherwise
+            // own binned-SAH BLAS per mesh (see build_sah_blas), or the ABI trees as they are
+            std::vector<spt_bvh_node> own_nodes;
+            std::vector<uint32_t> own_roots(s.n_meshes, 0u), tri_order(s.n_tris);
+            for (uint32_t i = 0; i < s.n_tris; ++i) tri_order[i] = i;
+            if (own_bvh) {
+                for (uint32_t i = 0; i < s.n_meshes; ++i) {
+                    own_roots[i] = (uint32_t)own_nodes.size();
+                    build_sah_blas(s.tri_pos, s.meshes[i].tri_first, s.meshes[i].tri_count, own_nodes, tri_order);
+                    const uint32_t depth = bvh_depth(own_nodes.data(), (uint32_t)own_nodes.size(), own_roots[i], s.n_tris, "device blas");
+                    if (tlas_depth + depth + 2 > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "device BVH deeper than the traversal stack (48 levels)");
+                }
+            }
+            const spt_bvh_node* blas_src = own_bvh ? own_nodes.data() : s.blas_nodes;
+            // triangles in leaf order of the tree that is walked, ABI index in the first vertex's pad lane
+            std::vector<spt_tri_pos> tri_blob(s.n_tris);
+            for (uint32_t i = 0; i < s.n_tris; ++i) {
+                tri_blob[i] = s.tri_pos[tri_order[i]];
+                std::memcpy(&tri_blob[i].pad0, &tri_order[i], 4);
+            }
             auto assemble = [&](bool n4) {
                 blob.clear();
                 std::vector<float4> wblas;
                 std::vector<float4> mesh_rec((size_t)s.n_meshes * 2, make_float4(0, 0, 0, 0));   // (root.lo, root ref) (root.hi, -)
                 for (uint32_t i = 0; i < s.n_meshes; ++i) {
-                    const spt_bvh_node& rn = s.blas_nodes[s.meshes[i].root];
+                    const uint32_t mesh_root = own_bvh ? own_roots[i] : s.meshes[i].root;
+                    const spt_bvh_node& rn = blas_src[mesh_root];
                     uint32_t root_ref;
                     if (n4) {
                         uint32_t need = 0;
-                        root_ref = build_n4(s.blas_nodes, s.meshes[i].root, wblas, &need, "blas");
+                        root_ref = build_n4(blas_src, mesh_root, wblas, &need, "blas");
                         if (tlas_depth + need + 2 > kLdsStack + kSpillStack)
                             fail(SPT_ERR_UNSUPPORTED, "4-wide BVH needs more than the traversal stack (48 entries)");
                     } else {
-                        const uint32_t sup = build_wide(s.blas_nodes, s.meshes[i].root, wblas, 0u, "blas");
+                        const uint32_t sup = build_wide(blas_src, mesh_root, wblas, 0u, "blas");
                         std::memcpy(&root_ref, &wblas[(size_t)sup * 4].w, 4);
                     }
                     float rf;
@@ -559,7 +716,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
                 d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
                 d.o_blas = append(wblas.data(), wblas.size() * 16);
-                d.o_tri = append(s.tri_pos, (size_t)s.n_tris * sizeof(spt_tri_pos));
+                d.o_tri = append(tri_blob.data(), (size_t)s.n_tris * sizeof(spt_tri_pos));
             };
             const size_t stack_bytes = (size_t)kLdsStack * 2 * kBlock * sizeof(uint32_t);   // (ref, t0) per LDS level
             assemble(false);

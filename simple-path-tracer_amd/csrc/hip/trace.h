@@ -131,10 +131,15 @@ SPT_DEV bool tri_test3(float4 a, float4 b, float4 c, const DRay& r, float* t, fl
 SPT_DEV bool tri_test(const float4* tri_pos, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
     return tri_test3(tri_pos[3 * tri], tri_pos[3 * tri + 1], tri_pos[3 * tri + 2], r, t, v_out, w_out);
 }
+// `slot` indexes the blob's triangle copy, which is in the order of the DEVICE-built BLAS; the
+// triangle's index in the ABI arrays (= BasicPrimitiveRef, the tie-rule key, the tri_attr index)
+// travels in the pad lane of its first vertex.
 template <bool kLds>
-SPT_DEV bool tri_test_geo(const DScene& sc, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
-    const uint32_t o = sc.o_tri + 3u * tri;
-    return tri_test3(geo_ld_tri<kLds>(sc, o), geo_ld_tri<kLds>(sc, o + 1), geo_ld_tri<kLds>(sc, o + 2), r, t, v_out, w_out);
+SPT_DEV bool tri_test_geo(const DScene& sc, uint32_t slot, const DRay& r, float* t, float* v_out, float* w_out, int32_t* id) {
+    const uint32_t o = sc.o_tri + 3u * slot;
+    const float4 a = geo_ld_tri<kLds>(sc, o);
+    *id = __float_as_int(a.w);
+    return tri_test3(a, geo_ld_tri<kLds>(sc, o + 1), geo_ld_tri<kLds>(sc, o + 2), r, t, v_out, w_out);
 }
 
 // Sphere::intersect_ray (sphere.rs:25-39)
@@ -359,9 +364,10 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
     walk_tree<kLds, true, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
-            bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
-            if (ok && t > orr.t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)i, h)))) {  // triangle.rs:187
-                h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)i; h.v = v; h.w = w;
+            int32_t id;
+            bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w, &id);
+            if (ok && t > orr.t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, id, h)))) {  // triangle.rs:187
+                h.t = t; h.inst = (int32_t)inst; h.prim = id; h.v = v; h.w = w;
             }
         }
         return false;
@@ -383,7 +389,8 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
     return walk_tree<kLds, false, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
-            if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w) && t > orr.t_min && t < t_max) return true;
+            int32_t id;
+            if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w, &id) && t > orr.t_min && t < t_max) return true;
         }
         return false;
     });
@@ -527,10 +534,11 @@ struct Walker {
                     float t, v, w;
                     DRay orr;
                     orr.o = oo; orr.d = od; orr.t_min = t_min;
-                    bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w);
+                    int32_t id;
+                    bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w, &id);
                     if (kClosest) {
-                        if (ok && t > t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)i, h)))) {
-                            h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)i; h.v = v; h.w = w;
+                        if (ok && t > t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, id, h)))) {
+                            h.t = t; h.inst = (int32_t)inst; h.prim = id; h.v = v; h.w = w;
                         }
                     } else if (ok && t > t_min && t < h.t) {
                         h.inst = (int32_t)inst;
