@@ -108,6 +108,15 @@ uint32_t bvh_depth(const spt_bvh_node* nodes, uint32_t n_nodes, uint32_t root, u
 // green (bit-identical films) in both modes.  Triangles are re-ordered into leaf order in the traversal
 // blob; each carries its ABI index in the pad lane of its first vertex (tie-rule key, tri_attr index).
 // Measured against libspt_host's trees: cfg2 38.4 -> 39.3 Gsamples/s, cfg5 761 -> 777 Msamples/s.
+// Outward padding of a device-side box along one axis.  It has to stay well below Ray::T_MIN_EPS (1e-4):
+// a ray leaving a convex object is rejected at the object's root box because it exits the box before
+// t_min - with 2^-12 of the extent the cube's rays entered the tree and the fused shade kernel went from
+// 2.6 to 3.5 ms (measured).  The slab test only fails for a ray that the triangle test accepts when the
+// hit lies within the rounding error of a box EDGE (two slabs barely overlapping), so this small pad
+// already makes a wrongly culled hit a ~1e-8-per-ray event.
+inline float box_pad(float lo, float hi) {
+    return (hi - lo) * 1.52587890625e-5f /* 2^-16 */ + std::max(std::fabs(lo), std::fabs(hi)) * 9.5367431640625e-7f /* 2^-20 */ + 1e-30f;
+}
 struct SahTri {
     float lo[3], hi[3], c[3];
     uint32_t id;
@@ -148,7 +157,7 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
             }
         spt_bvh_node nd;
         for (int k = 0; k < 3; ++k) {
-            const float pad = (hi[k] - lo[k]) * 1.52587890625e-5f + std::max(std::fabs(lo[k]), std::fabs(hi[k])) * 9.5367431640625e-7f + 1e-30f;
+            const float pad = box_pad(lo[k], hi[k]);
             nd.bmin[k] = lo[k] - pad;
             nd.bmax[k] = hi[k] + pad;
         }
@@ -233,7 +242,7 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
 // super-root inside `wide` (in wide-node units).  The first `bfs_nodes` wide nodes are numbered
 // breadth-first (they are the ones staged into LDS for large scenes), the subtrees below them
 // depth-first so that deep subtrees stay contiguous in memory.
-uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>& wide, uint32_t bfs_nodes, const char* what) {
+uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>& wide, uint32_t bfs_nodes, const char* what, bool pad_boxes = false) {
     auto leaf_ref = [&](const spt_bvh_node& nd) -> uint32_t {
         uint32_t cnt = nd.b & ~SPT_LEAF_FLAG;
         if (cnt > 15u) fail(SPT_ERR_UNSUPPORTED, std::string(what) + ": BVH leaf with more than 15 items");
@@ -243,6 +252,11 @@ uint32_t build_wide(const spt_bvh_node* nodes, uint32_t root, std::vector<float4
     auto set_child = [&](uint32_t w, int side, const spt_bvh_node& ch, uint32_t ref) {
         float4* f = &wide[(size_t)w * 4];
         float4 lo = make_float4(ch.bmin[0], ch.bmin[1], ch.bmin[2], 0.0f), hi = make_float4(ch.bmax[0], ch.bmax[1], ch.bmax[2], 0.0f);
+        if (pad_boxes && lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) {
+            const float px = box_pad(lo.x, hi.x), py = box_pad(lo.y, hi.y), pz = box_pad(lo.z, hi.z);
+            lo.x -= px; lo.y -= py; lo.z -= pz;
+            hi.x += px; hi.y += py; hi.z += pz;
+        }
         if (side == 0) { f[0].x = lo.x; f[0].y = lo.y; f[0].z = lo.z; f[1].x = hi.x; f[1].y = hi.y; f[1].z = hi.z; std::memcpy(&f[0].w, &ref, 4); }
         else { f[2] = lo; f[3] = hi; std::memcpy(&f[1].w, &ref, 4); }
     };
@@ -651,6 +665,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         d.env_h = s.env.height;
         for (int i = 0; i < 3; ++i) d.env_scale[i] = s.env.scale[i];
         d.stack_cap = cap;
+        d.fast_slab = own_bvh ? 1u : 0u;
         {
             // one float4 blob for everything the traversal touches: [tlas | instances | meshes | spheres | blas | tri]
             std::vector<float4> blob;
@@ -665,9 +680,13 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             d.tlas_root = 0;
             for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = 0.0f; d.tlas_hi[k] = 0.0f; }
             if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) {
-                const uint32_t sup = build_wide(s.tlas_nodes, 0, wtlas, 0xffffffffu, "tlas");
+                const uint32_t sup = build_wide(s.tlas_nodes, 0, wtlas, 0xffffffffu, "tlas", own_bvh);
                 std::memcpy(&d.tlas_root, &wtlas[(size_t)sup * 4].w, 4);      // left child of the super-root = real root
-                for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = s.tlas_nodes[0].bmin[k]; d.tlas_hi[k] = s.tlas_nodes[0].bmax[k]; }
+                for (int k = 0; k < 3; ++k) {
+                    const float pad = own_bvh ? box_pad(s.tlas_nodes[0].bmin[k], s.tlas_nodes[0].bmax[k]) : 0.0f;
+                    d.tlas_lo[k] = s.tlas_nodes[0].bmin[k] - pad;
+                    d.tlas_hi[k] = s.tlas_nodes[0].bmax[k] + pad;
+                }
             }
             // BLAS: 2-wide full-precision nodes when the whole scene fits LDS, compressed 4-wide nodes otherwise
             // own binned-SAH BLAS per mesh (see build_sah_blas), or the ABI trees as they are
@@ -686,8 +705,11 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             // triangles in leaf order of the tree that is walked, ABI index in the first vertex's pad lane
             std::vector<spt_tri_pos> tri_blob(s.n_tris);
             for (uint32_t i = 0; i < s.n_tris; ++i) {
-                tri_blob[i] = s.tri_pos[tri_order[i]];
-                std::memcpy(&tri_blob[i].pad0, &tri_order[i], 4);
+                const spt_tri_pos& src = s.tri_pos[tri_order[i]];
+                spt_tri_pos& dst = tri_blob[i];
+                dst = src;
+                for (int k = 0; k < 3; ++k) { dst.p1[k] = src.p1[k] - src.p0[k]; dst.p2[k] = src.p2[k] - src.p0[k]; }   // e1, e2 of triangle.rs:125-126
+                std::memcpy(&dst.pad0, &tri_order[i], 4);
             }
             auto assemble = [&](bool n4) {
                 blob.clear();
@@ -910,7 +932,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         sc->qb[4].ensure(cap * 8);
         sc->hit_f4.ensure(cap * 16);
         sc->hit_inst.ensure(cap * 4);
-        const bool fused = sc->lds_geo && std::getenv("SPT_NO_FUSED") == nullptr;   // see k_shade<.., kFused>
+        // see k_shade<.., kFused>.  Only the lean k_shade<0> variant gains: with the general kernel's 220+ VGPRs
+        // the two traversals run at 2 waves / SIMD and cfg4 is faster un-fused (4.30 vs 4.00 Gsamples/s, measured)
+        const bool fused = sc->lds_geo && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
         if (fused) {
             sc->hit_f4_next.ensure(cap * 16);
             sc->hit_inst_next.ensure(cap * 4);
@@ -1019,11 +1043,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     // (qa, hits) for even b and in (qb, hits_next) for odd b
                     RenderCtx rb = rc;
                     if (b & 1u) { std::swap(rb.qa, rb.qb); std::swap(rb.hits, rb.hits_next); }
-#define SPT_LAUNCH_FUSED(FEAT)                                                                                                       \
-    if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);          \
-    else hipLaunchKernelGGL((k_shade<FEAT, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
-                    if (sc->simple) { SPT_LAUNCH_FUSED(0) } else if (!sc->textured) { SPT_LAUNCH_FUSED(1) } else { SPT_LAUNCH_FUSED(2) }
-#undef SPT_LAUNCH_FUSED
+                    if (b == 0) hipLaunchKernelGGL((k_shade<0, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                    else hipLaunchKernelGGL((k_shade<0, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
                     end();
                     continue;
                 }

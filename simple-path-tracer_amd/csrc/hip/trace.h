@@ -48,6 +48,7 @@ struct DScene {
     uint32_t geo_f4;           // blob length in float4
     uint32_t lds_f4;           // staged prefix length in float4 (== geo_f4 for k_*<true>)
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
+    uint32_t fast_slab;        // device-built (padded) trees: box tests only cull, so 1/d may be v_rcp_f32 (1 ulp)
     uint32_t tlas_root;        // ref of the TLAS root (wide-node index or leaf ref)
     float tlas_lo[3], tlas_hi[3];  // its box
     // image textures (k_shade<2, .> only; all null otherwise), see shading.h "textures"
@@ -92,7 +93,13 @@ SPT_DEV void stage_geometry(const DScene& sc) {
     __syncthreads();
 }
 
-SPT_DEV f3 recip3(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+// 1/d for the slab tests.  With the caller's exact trees (SPT_REFERENCE_BVH=1) this is the IEEE division the
+// oracle's reciprocal mode performs; with the library's own padded trees the boxes only cull and the
+// hardware reciprocal (1 ulp, one instruction instead of ~10 per component) is enough.
+SPT_DEV f3 recip3(const DScene& sc, f3 d) {
+    if (sc.fast_slab) return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
 
 // Bbox::intersect_test (bbox.rs:63-93) with o, 1/d
 SPT_DEV bool slab_test(float4 lo, float4 hi, f3 o, f3 inv_d, float t_min, float t_max) {
@@ -128,10 +135,28 @@ SPT_DEV bool tri_test3(float4 a, float4 b, float4 c, const DRay& r, float* t, fl
     return (det != 0.0f) & (v >= 0.0f) & (w >= 0.0f) & (u >= 0.0f);
 }
 
+// the same with the two edge vectors already subtracted (the traversal blob stores p0, p1 - p0, p2 - p0:
+// the identical f32 differences, computed once at scene creation instead of per test)
+SPT_DEV bool tri_test_edges(float4 a, float4 b, float4 c, const DRay& r, float* t, float* v_out, float* w_out) {
+    f3 p0 = mk3(a), e1 = mk3(b), e2 = mk3(c);
+    f3 q = cross(r.d, e2);
+    float det = dot(e1, q);
+    float inv = 1.0f / det;
+    f3 s = r.o - p0;
+    float v = dot(s, q) * inv;
+    f3 rr = cross(s, e1);
+    float w = dot(r.d, rr) * inv;
+    float u = 1.0f - v - w;
+    *t = dot(e2, rr) * inv;
+    *v_out = v;
+    *w_out = w;
+    return (det != 0.0f) & (v >= 0.0f) & (w >= 0.0f) & (u >= 0.0f);
+}
+
 SPT_DEV bool tri_test(const float4* tri_pos, uint32_t tri, const DRay& r, float* t, float* v_out, float* w_out) {
     return tri_test3(tri_pos[3 * tri], tri_pos[3 * tri + 1], tri_pos[3 * tri + 2], r, t, v_out, w_out);
 }
-// `slot` indexes the blob's triangle copy, which is in the order of the DEVICE-built BLAS; the
+// `slot` indexes the blob's triangle copy (p0, p1 - p0, p2 - p0), which is in the order of the DEVICE-built BLAS; the
 // triangle's index in the ABI arrays (= BasicPrimitiveRef, the tie-rule key, the tri_attr index)
 // travels in the pad lane of its first vertex.
 template <bool kLds>
@@ -139,7 +164,7 @@ SPT_DEV bool tri_test_geo(const DScene& sc, uint32_t slot, const DRay& r, float*
     const uint32_t o = sc.o_tri + 3u * slot;
     const float4 a = geo_ld_tri<kLds>(sc, o);
     *id = __float_as_int(a.w);
-    return tri_test3(a, geo_ld_tri<kLds>(sc, o + 1), geo_ld_tri<kLds>(sc, o + 2), r, t, v_out, w_out);
+    return tri_test_edges(a, geo_ld_tri<kLds>(sc, o + 1), geo_ld_tri<kLds>(sc, o + 2), r, t, v_out, w_out);
 }
 
 // Sphere::intersect_ray (sphere.rs:25-39)
@@ -359,7 +384,7 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
     }
     const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
     const uint32_t root = __float_as_uint(rlo.w);
-    const f3 inv_o = recip3(orr.d);
+    const f3 inv_o = recip3(sc, orr.d);
     if (!root_hit<true>(rlo, rhi, orr.o, inv_o, orr.t_min, h.t)) return;
     walk_tree<kLds, true, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
@@ -384,7 +409,7 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
     }
     const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
     const uint32_t root = __float_as_uint(rlo.w);
-    const f3 inv_o = recip3(orr.d);
+    const f3 inv_o = recip3(sc, orr.d);
     if (!root_hit<false>(rlo, rhi, orr.o, inv_o, orr.t_min, t_max)) return false;
     return walk_tree<kLds, false, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
@@ -411,7 +436,7 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
     if (sc.aggregate == SPT_AGGREGATE_GROUP) {
         for (uint32_t i = 0; i < sc.n_instances; ++i) instance_closest<kLds>(sc, i, ray, h, st);
     } else if (sc.n_tlas_nodes > 0) {
-        const f3 inv_w = recip3(ray.d);
+        const f3 inv_w = recip3(sc, ray.d);
         const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
         if (root_hit<true>(tlo, thi, ray.o, inv_w, ray.t_min, h.t))
         walk_tree<kLds, true, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
@@ -434,7 +459,7 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
         return false;
     }
     if (sc.n_tlas_nodes == 0) return false;
-    const f3 inv_w = recip3(ray.d);
+    const f3 inv_w = recip3(sc, ray.d);
     const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
     if (!root_hit<false>(tlo, thi, ray.o, inv_w, ray.t_min, t_max)) return false;
     return walk_tree<kLds, false, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
@@ -465,7 +490,7 @@ struct Walker {
     SPT_DEV void start(const DScene& sc, const DRay& r, float t_max, uint2* spill_mem) {
         st.spill = spill_mem;
         o = r.o; d = r.d; t_min = r.t_min;
-        inv_w = recip3(r.d);
+        inv_w = recip3(sc, r.d);
         h.t = t_max; h.inst = -1; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
         st.sp = 0;
         done = false;
@@ -586,7 +611,7 @@ struct Walker {
                 return;
             }
             oo = orr.o; od = orr.d;
-            inv_o = recip3(orr.d);
+            inv_o = recip3(sc, orr.d);
             const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
             if (!root_hit<kClosest>(rlo, rhi, oo, inv_o, t_min, h.t)) return;   // stays in phase 0: next instance
             cur = __float_as_uint(rlo.w);
