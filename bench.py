@@ -125,6 +125,16 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    film = None
+    if dist is not None:
+        name = [None]
+        if rank == 0:
+            film = spt.SharedFilm(args.height, args.width, create=True)
+            name[0] = film.name
+        dist.broadcast_object_list(name, src=0)
+        if rank != 0:
+            film = spt.SharedFilm(args.height, args.width, name=name[0])
+
     kernel_ms = np.zeros(spt.N_KERNELS)
     kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
     stats_last = None
@@ -140,8 +150,11 @@ def main():
                 kernel_ms[k] += st.kernel_ms[k]
                 kernel_launches[k] += st.kernel_launches[k]
         stats_last = st
-        # host-side gather of the shards (no reduction: rows are disjoint)
-        return spt.gather_shards(shard, args.height, args.width, rank, world, strip_rows, dist)
+        # image assembly: every rank writes its (disjoint) rows into the node's shared-memory film - no
+        # collective on the data path
+        if film is not None:
+            film.write_shard(shard, rank, world, strip_rows)
+        return shard
 
     for _ in range(args.warmup):
         step(False)
@@ -173,6 +186,7 @@ def main():
         ext, hits0, verts = seg_c - smp, st.primary_hits, st.path_vertices
         n_pix = len(spt.shard_rows(args.height, 0, world, strip_rows)) * args.width
         passes = max(int(kernel_launches[0]) // n_prof, 1)
+        RNAME = {"shade_first": "k_shade"}                           # kernel symbol behind a class name
         # ALGORITHMIC bytes each kernel class moves per step (DESIGN.md "Kernels and rooflines"):
         # queue records written/read once + radiance-slot / film read-modify-writes; scene geometry of
         # this workload (< 2 KB) is LDS-resident and counted as 0 ("count it once").
@@ -180,16 +194,22 @@ def main():
         # path-to-extend records do not exist; it reads the vertices, writes the next bounce's vertices and
         # read-modify-writes one radiance slot per (unoccluded) shadow ray
         fused = int(kernel_launches[2]) == 0 and int(kernel_launches[3]) == 0
+        seg_s0, verts1 = st.shadow_first, st.vertices_second        # bounce 0: shadow rays issued, vertices kept for bounce 1
+        later = verts - hits0                                        # path vertices of bounces >= 1
         alg = {
             "primary": hits0 * (S_PATH0 + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
-            "shade": (hits0 * (S_PATH0 + S_HIT) + 2 * (verts - hits0) * (S_PATH + S_HIT) + seg_s * 2 * S_RAD) if fused else
-                     hits0 * (S_PATH0 + S_HIT) + (verts - hits0) * (S_PATH + S_HIT) + seg_s * S_SHADOW + ext * S_PATH,
+            # bounce-0 shade launches (one per pass): read the compact hit records, (fused) write the kept bounce-1
+            # vertices and read-modify-write a radiance slot per shadow ray, (un-fused) write shadow + path records
+            "shade_first": (hits0 * (S_PATH0 + S_HIT) + verts1 * (S_PATH + S_HIT) + seg_s0 * 2 * S_RAD) if fused else
+                           hits0 * (S_PATH0 + S_HIT) + seg_s0 * S_SHADOW + min(ext, hits0) * S_PATH,
+            "shade": (later * (S_PATH + S_HIT) + (later - verts1) * (S_PATH + S_HIT) + (seg_s - seg_s0) * 2 * S_RAD) if fused else
+                     later * (S_PATH + S_HIT) + (seg_s - seg_s0) * S_SHADOW + max(ext - hits0, 0) * S_PATH,
             "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
             "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
             "resolve": hits0 * S_RAD + passes * n_pix * 2 * S_RAD,
         }
         kern = {}
-        for k in range(5):
+        for k in (0, 6, 1, 2, 3, 4):
             name = spt.KERNEL_NAMES[k]
             if kernel_launches[k] == 0:
                 continue
@@ -206,11 +226,11 @@ def main():
         # separate rocprofv3 --pmc run of this same command and committed under profiles/ (tools/pmc_traffic.py)
         traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r01_traffic_bench.json")
         if os.path.exists(traffic_src) and world == 1 and args.samples_per_pass == 0 and args.spp == 256:
-            tk = json.load(open(traffic_src))["kernels"].get("k_" + dom_name)
-            if tk and tk["launches"] == dom.get("launches_per_step"):
+            tk = json.load(open(traffic_src))["kernels"].get("k_" + dom_name)   # "k_shade_first": bounce-0 instances
+            if tk and tk["launches"] == dom.get("launches_per_step"):   # (per-template-instance entries: see tools/pmc_traffic.py)
                 traffic = round(tk["hbm_bytes_per_launch"] / 1e6, 3)
         roofline = {
-            "bound": "hbm", "kernel": "k_" + dom_name, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": RNAME.get(dom_name, "k_" + dom_name) + (" (bounce 0)" if dom_name == "shade_first" else ""), "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_unit": "MB per launch (PMC, profiles/r01_traffic_bench.json)",
             "avg_launch_ms": dom["avg_launch_ms"], "alg_MB_per_launch": dom["alg_MB_per_launch"],
             "kernels": kern,
@@ -228,7 +248,8 @@ def main():
                                    "%dx%d @ %d spp (%d spp per GPU-share), max_depth %d, recurrence sampler"
                                    % (args.width, args.height, renderer.spp, args.spp, renderer.max_depth),
                        "width": args.width, "height": args.height, "spp": renderer.spp, "seed": 1,
-                       "sharding": "interleaved %d-row strips over %d rank(s), host-side gather" % (strip_rows, world),
+                       "sharding": "interleaved %d-row strips over %d rank(s); each rank writes its rows into one shared-memory film "
+                                   "(no collective)" % (strip_rows, world),
                        "segments_per_sample": round((seg_c + seg_s) / max(smp, 1), 4),
                        "primary_hit_fraction": round(hits0 / max(smp, 1), 4)},
             "roofline": roofline,
@@ -240,6 +261,10 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         barrier()
+        if rank == 0 and film is not None:   # the assembled image: every pixel was written by exactly one rank
+            assert np.isfinite(film.film).all() and float(film.film.max()) > 0.0
+        barrier()
+        film.close()
         dist.destroy_process_group()
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 3
+#define SPT_ABI_VERSION 4
 
 typedef int32_t spt_status;
 enum {
@@ -294,8 +294,9 @@ typedef struct spt_render_params {
 } spt_render_params;
 enum { SPT_RENDER_PROFILE = 1u /* time each kernel class with HIP events */ };
 
-#define SPT_N_KERNELS 6
-enum { SPT_K_PRIMARY = 0, SPT_K_SHADE = 1, SPT_K_SHADOW = 2, SPT_K_EXTEND = 3, SPT_K_RESOLVE = 4, SPT_K_OTHER = 5 };
+#define SPT_N_KERNELS 7
+/* SHADE_FIRST: the shade launches of bounce 0 (one per pass, nearly all path vertices); SHADE: bounces >= 1 */
+enum { SPT_K_PRIMARY = 0, SPT_K_SHADE = 1, SPT_K_SHADOW = 2, SPT_K_EXTEND = 3, SPT_K_RESOLVE = 4, SPT_K_OTHER = 5, SPT_K_SHADE_FIRST = 6 };
 typedef struct spt_render_stats {
     uint64_t samples;              /* camera samples traced = rows*width*spp               */
     uint64_t segments_closest;     /* closest-hit ray segments (primary + extension)       */
@@ -305,6 +306,8 @@ typedef struct spt_render_stats {
     uint32_t kernel_launches[SPT_N_KERNELS];
     uint64_t primary_hits;         /* camera samples whose primary ray hit something           */
     uint64_t path_vertices;        /* records consumed by the shade stage over all bounces     */
+    uint64_t shadow_first;         /* any-hit segments issued by the bounce-0 shade launches   */
+    uint64_t vertices_second;      /* path vertices of bounce 1 (= extension rays of bounce 0 that were kept) */
 } spt_render_stats;
 
 /* Closest-hit record: what BvhAccel/Group::intersect leave in `Intersection`

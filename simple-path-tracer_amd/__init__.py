@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 3
+SPT_ABI_VERSION = 4
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -151,8 +151,8 @@ class Camera(C.Structure):
 
 SAMPLER_RANDOM, SAMPLER_JITTERED, SAMPLER_RECURRENCE = 0, 1, 2
 RENDER_PROFILE = 1
-N_KERNELS = 6
-KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other")
+N_KERNELS = 7
+KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other", "shade_first")
 
 
 class RenderParams(C.Structure):
@@ -166,7 +166,7 @@ class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments_closest", C.c_uint64), ("segments_shadow", C.c_uint64),
                 ("gpu_ms", C.c_double), ("kernel_ms", C.c_double * N_KERNELS),
                 ("kernel_launches", C.c_uint32 * N_KERNELS), ("primary_hits", C.c_uint64),
-                ("path_vertices", C.c_uint64)]
+                ("path_vertices", C.c_uint64), ("shadow_first", C.c_uint64), ("vertices_second", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("instance", "<i4"), ("prim", "<i4"), ("v", "<f4"), ("w", "<f4")])
@@ -505,6 +505,51 @@ def gather_shards(shard: np.ndarray, height: int, width: int, rank: int, world: 
         return full
     dist.gather(t, None, dst=0)
     return None
+
+
+class SharedFilm:
+    """The full (H, W, 3) f32 film in POSIX shared memory, one mapping per rank of a node.
+
+    Every rank writes the image rows of its own shard (disjoint interleaved strips), so assembling the
+    image needs no collective and no copy through a socket: it is the multi-process counterpart of the
+    reference's UnsafeFilm (src/core/film.rs:101-116), where all render threads write disjoint pixels of one
+    film.  Rank 0 creates the segment and passes `name` to the others (e.g. dist.broadcast_object_list)."""
+
+    def __init__(self, height: int, width: int, name: Optional[str] = None, create: bool = False):
+        from multiprocessing import shared_memory
+        self.height, self.width = height, width
+        nbytes = height * width * 3 * 4
+        if create:
+            self._shm = shared_memory.SharedMemory(create=True, size=nbytes, name=name)
+        else:
+            self._shm = shared_memory.SharedMemory(name=name)
+            # the creating rank owns the segment: keep this process' resource tracker from unlinking it
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
+        self._owner = create
+        self.name = self._shm.name
+        self.film = np.ndarray((height, width, 3), dtype=np.float32, buffer=self._shm.buf)
+
+    def write_shard(self, shard: np.ndarray, rank: int, world: int, strip_rows: int) -> None:
+        rows = shard_rows(self.height, rank, world, strip_rows)
+        assert shard.shape == (len(rows), self.width, 3), (shard.shape, len(rows))
+        # rows of one strip are contiguous in both arrays: one memcpy per strip
+        k = 0
+        while k < len(rows):
+            e = k
+            while e + 1 < len(rows) and rows[e + 1] == rows[e] + 1:
+                e += 1
+            self.film[rows[k]:rows[e] + 1] = shard[k:e + 1]
+            k = e + 1
+
+    def close(self) -> None:
+        self.film = None
+        self._shm.close()
+        if self._owner:
+            self._shm.unlink()
 
 
 def device_detmath(fn: int, a: np.ndarray, b: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:

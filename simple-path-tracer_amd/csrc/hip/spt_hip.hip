@@ -1025,7 +1025,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         HIP_CHECK(hipEventRecord(ev_total0, st));
         HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
         std::vector<uint32_t> h_counts;
-        uint64_t seg_closest = 0, seg_shadow = 0, primary_hits = 0, path_vertices = 0;
+        uint64_t seg_closest = 0, seg_shadow = 0, primary_hits = 0, path_vertices = 0, shadow_first = 0, vertices_second = 0;
         for (uint32_t s0 = 0; s0 < p.spp; s0 += spp_pass) {
             rc.pass_first = s0;
             rc.pass_samples = std::min(spp_pass, p.spp - s0);
@@ -1037,7 +1037,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             else hipLaunchKernelGGL(k_primary<false>, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
             end();
             for (uint32_t b = 0; b < p.max_depth; ++b) {
-                begin(SPT_K_SHADE);
+                begin(b == 0 ? SPT_K_SHADE_FIRST : SPT_K_SHADE);
                 if (fused) {
                     // shade + shadow + extend of this bounce in one kernel; vertices of bounce b live in
                     // (qa, hits) for even b and in (qb, hits_next) for odd b
@@ -1086,6 +1086,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     return t;
                 };
                 primary_hits += qsum(0, Q_HIT);
+                shadow_first += qsum(0, Q_SHADOW);
+                if (p.max_depth > 1) vertices_second += qsum(1, Q_HIT);
                 for (uint32_t b = 0; b < p.max_depth; ++b) {
                     path_vertices += qsum(b, Q_HIT);
                     seg_shadow += qsum(b, Q_SHADOW);
@@ -1106,6 +1108,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             stats->segments_shadow = seg_shadow;
             stats->primary_hits = primary_hits;
             stats->path_vertices = path_vertices;
+            stats->shadow_first = shadow_first;
+            stats->vertices_second = vertices_second;
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_total0, ev_total1));
             stats->gpu_ms = ms;

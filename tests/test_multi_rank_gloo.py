@@ -38,14 +38,28 @@ def _worker(rank, world, port, out_path):
     t0 = time.perf_counter()
     shard, _ = u.oracle_render(sc, r, w, h, camera="main", shard_index=rank, shard_count=world, strip_rows=strip, threads=2)
     full = spt.gather_shards(shard, h, w, rank, world, strip, dist)
+    # the collective-free assembly bench.py uses: one shared-memory film, every rank writes its own rows
+    name = [None]
+    film = None
+    if rank == 0:
+        film = spt.SharedFilm(h, w, create=True)
+        film.film[:] = -1.0
+        name[0] = film.name
+    dist.broadcast_object_list(name, src=0)
+    dist.barrier()                      # the fill above is done before anyone writes
+    if rank != 0:
+        film = spt.SharedFilm(h, w, name=name[0])
+    film.write_shard(shard, rank, world, strip)
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     if rank == 0:
         ref, _ = u.oracle_render(sc, r, w, h, camera="main", threads=2)
-        np.savez(out_path, full=full, ref=ref, dt=dt.numpy())
+        np.savez(out_path, full=full, ref=ref, dt=dt.numpy(), shared=np.array(film.film))
     else:
         assert full is None
+    dist.barrier()
+    film.close()
     dist.destroy_process_group()
 
 
@@ -57,6 +71,7 @@ def test_two_rank_shard_and_gather_is_bit_identical(tmp_path):
     z = np.load(out)
     assert z["full"].shape == (40, 48, 3)
     assert np.array_equal(z["full"].view(np.uint32), z["ref"].view(np.uint32))
+    assert np.array_equal(z["shared"].view(np.uint32), z["ref"].view(np.uint32))
     assert z["dt"][0] > 0
 
 

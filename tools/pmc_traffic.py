@@ -16,6 +16,9 @@ def per_kernel(path, counter):
     df = pd.read_csv(path)
     df = df[df["Counter_Name"] == counter]
     df["k"] = df["Kernel_Name"].str.extract(r"(k_\w+)")
+    # the bounce-0 instances of k_shade (second template argument kFirst = true) are a class of their own
+    first = df["Kernel_Name"].str.contains(r"k_shade<\d+, true", regex=True)
+    df.loc[first, "k"] = "k_shade_first"
     df = df.dropna(subset=["k"])
     per_dispatch = df.groupby(["k", "Dispatch_Id"])["Counter_Value"].sum().reset_index()
     g = per_dispatch.groupby("k")["Counter_Value"]
