@@ -48,5 +48,6 @@ struct HostScene {
 
 HostScene* load_scene_file(const std::string& path);
 void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
+void decode_png_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
 
 }  // namespace spt_host

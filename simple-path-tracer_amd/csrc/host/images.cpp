@@ -82,6 +82,10 @@ void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, 
     size_t n;
     while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
     std::fclose(f);
+    decode_png_rgba8(d, path, width, height, texels);
+}
+
+void decode_png_rgba8(const std::vector<uint8_t>& d, const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0)
         throw HostError(SPT_HOST_ERR_UNSUPPORTED, "image '" + path + "': only PNG files are decoded (JPEG decoding is not bit-reproducible across decoders; convert the asset)");

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <set>
 #include <sstream>
@@ -301,6 +302,74 @@ void calc_tangents(ObjMesh& m) {
         }
 }
 
+
+// ---- glTF 2.0 import helpers (role of the `gltf` crate's import(), reference src/loader/gltf.rs:19-20) ----
+std::vector<uint8_t> base64_decode(const std::string& in, const std::string& what) {
+    std::vector<uint8_t> out;
+    uint32_t acc = 0;
+    int bits = 0;
+    for (char ch : in) {
+        int v;
+        if (ch >= 'A' && ch <= 'Z') v = ch - 'A';
+        else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26;
+        else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+        else if (ch == '+' || ch == '-') v = 62;
+        else if (ch == '/' || ch == '_') v = 63;
+        else if (ch == '=' || ch == '\n' || ch == '\r') continue;
+        else throw HostError(SPT_HOST_ERR_PARSE, what + ": bad base64 data");
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)((acc >> bits) & 0xffu)); }
+    }
+    return out;
+}
+std::vector<uint8_t> read_bytes(const std::string& path) {
+    std::string s = read_file(path);
+    return std::vector<uint8_t>(s.begin(), s.end());
+}
+// a uri of a buffer or image: "data:<mime>;base64,<payload>" or a path relative to the glTF file
+std::vector<uint8_t> load_uri(const std::string& uri, const std::string& gltf_path) {
+    if (uri.rfind("data:", 0) == 0) {
+        size_t c = uri.find(',');
+        if (c == std::string::npos || uri.find(";base64") == std::string::npos || uri.find(";base64") > c)
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "gltf: only base64 data URIs are supported");
+        return base64_decode(uri.substr(c + 1), "gltf data URI");
+    }
+    return read_bytes(with_file_name(gltf_path, uri));
+}
+// TriMesh::calc_normals (src/primitive/triangle.rs:305-337)
+void calc_normals(ObjMesh& m) {
+    size_t nv = m.pos.size();
+    std::vector<V3> sum(nv);
+    std::vector<int> deg(nv, 0);
+    for (size_t t = 0; t + 2 < m.idx.size(); t += 3) {
+        uint32_t i0 = m.idx[t], i1 = m.idx[t + 1], i2 = m.idx[t + 2];
+        V3 n = normalize(cross(m.pos[i1] - m.pos[i0], m.pos[i2] - m.pos[i0]));
+        for (uint32_t i : {i0, i1, i2}) { sum[i] = sum[i] + n; deg[i]++; }
+    }
+    for (size_t i = 0; i < nv; ++i)
+        if (deg[i] != 0) m.nrm[i] = normalize(sum[i] / (float)deg[i]);
+}
+struct M4 {   // column-major, glam Mat4
+    float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
+inline M4 operator*(const M4& a, const M4& b) {   // glam Mat4 * Mat4: each column of b transformed by a
+    M4 r;
+    for (int c = 0; c < 4; ++c)
+        for (int k = 0; k < 4; ++k)
+            r.m[4 * c + k] = ((a.m[k] * b.m[4 * c] + a.m[4 + k] * b.m[4 * c + 1]) + a.m[8 + k] * b.m[4 * c + 2]) + a.m[12 + k] * b.m[4 * c + 3];
+    return r;
+}
+double jnum(const JsonValue* v, double fb) { return (v && v->is_number()) ? v->as_double() : fb; }
+bool jvec(const JsonValue* v, size_t n, float* out) {
+    if (!v || v->kind != JsonValue::Array || v->arr.size() != n) return false;
+    for (size_t i = 0; i < n; ++i) {
+        if (!v->arr[i].is_number()) return false;
+        out[i] = (float)v->arr[i].as_double();
+    }
+    return true;
+}
+
 struct PrimRec { uint32_t type; uint32_t id; Box box; };
 struct SurfaceRec { uint32_t index; bool emissive; };
 
@@ -389,6 +458,9 @@ struct SceneBuilder {
         uint32_t w = 0, h = 0;
         std::vector<uint32_t> lvl;
         read_png_rgba8(file, &w, &h, &lvl);
+        return add_image_pixels(file, w, h, lvl);
+    }
+    uint32_t add_image_pixels(const std::string& key, uint32_t w, uint32_t h, std::vector<uint32_t> lvl) {
         spt_image im;
         im.first_level = (uint32_t)hs.image_levels.size();
         im.n_levels = 0;
@@ -417,7 +489,7 @@ struct SceneBuilder {
             w = nw; h = nh;
         }
         hs.images.push_back(im);
-        image_ids[file] = (uint32_t)hs.images.size() - 1;
+        image_ids[key] = (uint32_t)hs.images.size() - 1;
         return (uint32_t)hs.images.size() - 1;
     }
 
@@ -440,6 +512,11 @@ struct SceneBuilder {
         V3 eye = p.get_float3("eye"), fwd = p.get_float3("forward"), up = p.get_float3("up");
         float fov = p.get_float("fov") * 3.14159265358979323846f / 180.0f;
         if (hs.camera_index.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated camera name '" + name + "'");
+        add_camera(name, eye, fwd, up, fov);
+        p.check_unused();
+    }
+    // PerspectiveCamera::new (src/camera/perspective.rs:15-27), fov in radians
+    void add_camera(const std::string& name, V3 eye, V3 fwd, V3 up, float fov) {
         spt_camera c;
         V3 f = normalize(fwd);
         V3 r = normalize(cross(f, up));
@@ -451,7 +528,6 @@ struct SceneBuilder {
         c.half_cot_half_fov = 0.5f / std::tan(fov * 0.5f);
         hs.camera_index[name] = hs.cameras.size();
         hs.cameras.push_back(c);
-        p.check_unused();
     }
 
     // texture::create_texture_from_params (src/texture/mod.rs:210-243)
@@ -831,7 +907,13 @@ struct SceneBuilder {
         std::string pn = p.get_str("primitive");
         auto pi = prims.find(pn);
         if (pi == prims.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no primitive named '" + pn + "'");
+        if (instances.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated instance name '" + name + "'");
+        instances[name] = make_instance(name, trans, pi->second, surf);
+        p.check_unused();
+    }
 
+    // Instance::new (src/primitive/instance.rs:53-85)
+    InstRec make_instance(const std::string& name, const Affine& trans, const PrimRec& prim, uint32_t surf) {
         InstRec rec;
         rec.name = name;
         rec.trans = trans;
@@ -847,20 +929,18 @@ struct SceneBuilder {
         put(in.fwd, trans);
         const V3 nc[3] = {it3.c0, it3.c1, it3.c2};
         for (int c = 0; c < 3; ++c) { in.nrm[3 * c] = nc[c].x; in.nrm[3 * c + 1] = nc[c].y; in.nrm[3 * c + 2] = nc[c].z; }
-        in.prim_type = pi->second.type;
-        in.prim_id = pi->second.id;
+        in.prim_type = prim.type;
+        in.prim_id = prim.id;
         in.surface = surf;
         in.light = -1;
         // Bbox::transformed_by (src/core/bbox.rs:40-61): the 8 corners
-        const Box& pb = pi->second.box;
+        const Box& pb = prim.box;
         Box wb;
         for (int c = 0; c < 8; ++c)
             wb.grow(trans.point({(c & 4) ? pb.hi.x : pb.lo.x, (c & 2) ? pb.hi.y : pb.lo.y, (c & 1) ? pb.hi.z : pb.lo.z}));
         in.bmin[0] = wb.lo.x; in.bmin[1] = wb.lo.y; in.bmin[2] = wb.lo.z;
         in.bmax[0] = wb.hi.x; in.bmax[1] = wb.hi.y; in.bmax[2] = wb.hi.z;
-        if (instances.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated instance name '" + name + "'");
-        instances[name] = rec;
-        p.check_unused();
+        return rec;
     }
 
     // light::create_light_from_params (src/light/mod.rs:37-59)
@@ -979,6 +1059,394 @@ struct SceneBuilder {
     }
 
     // PrimitiveT::surface_area for an instance under `trans` (Instance/TriMesh/Sphere ::surface_area)
+    // ---- loader::gltf::load_scene_resources (src/loader/gltf.rs:19-43) -----------------------------------
+    // Everything the glTF defines is resolved inside the glTF's own namespace; cameras, instances and
+    // lights are then merged by name, existing (JSON) names winning (SceneResources::merge,
+    // src/core/scene_resources.rs:264-310).
+    struct GltfTex { uint32_t node; bool constant; V3 value; float alpha; };
+    GltfTex gl_scalar(V3 v) {
+        uint32_t n = add_tex_node(SPT_TEX_SCALAR);
+        hs.textures[n].value[0] = v.x; hs.textures[n].value[1] = v.y; hs.textures[n].value[2] = v.z;
+        return {n, true, v, 1.0f};
+    }
+    GltfTex gl_binary(uint32_t op, const GltfTex& a, const GltfTex& b) {
+        GltfTex r;
+        r.node = add_tex_node(op, a.node, b.node);
+        r.constant = a.constant && b.constant;
+        if (op == SPT_TEX_MUL) { r.value = a.value * b.value; r.alpha = a.alpha * b.alpha; }
+        else { r.value = a.value - b.value; r.alpha = a.alpha - b.alpha; }
+        return r;
+    }
+    GltfTex gl_srgb(const GltfTex& a) {
+        GltfTex r = a;
+        r.node = add_tex_node(SPT_TEX_SRGB, a.node);
+        r.value = {srgb_to_linear(a.value.x), srgb_to_linear(a.value.y), srgb_to_linear(a.value.z)};
+        return r;
+    }
+    static float gl_chan(const GltfTex& t, uint32_t chan) {
+        return chan == SPT_CHAN_R ? t.value.x : (chan == SPT_CHAN_G ? t.value.y : (chan == SPT_CHAN_B ? t.value.z : t.alpha));
+    }
+
+    void import_gltf(const std::string& file) {
+        // --- container: .gltf (JSON) or .glb (JSON chunk + BIN chunk)
+        std::vector<uint8_t> raw = read_bytes(file);
+        std::string json_text;
+        std::vector<uint8_t> glb_bin;
+        if (raw.size() >= 12 && std::memcmp(raw.data(), "glTF", 4) == 0) {
+            size_t p = 12;
+            while (p + 8 <= raw.size()) {
+                uint32_t len, type;
+                std::memcpy(&len, &raw[p], 4);
+                std::memcpy(&type, &raw[p + 4], 4);
+                if (p + 8 + (size_t)len > raw.size()) throw HostError(SPT_HOST_ERR_PARSE, "gltf '" + file + "': truncated GLB chunk");
+                if (type == 0x4E4F534Au) json_text.assign((const char*)&raw[p + 8], len);
+                else if (type == 0x004E4942u && glb_bin.empty()) glb_bin.assign(raw.begin() + p + 8, raw.begin() + p + 8 + len);
+                p += 8 + (size_t)len;
+            }
+        } else {
+            json_text.assign(raw.begin(), raw.end());
+        }
+        JsonValue doc;
+        try {
+            doc = JsonParser(json_text).parse();
+        } catch (const std::exception& e) {
+            throw HostError(SPT_HOST_ERR_PARSE, "gltf '" + file + "': " + e.what());
+        }
+        if (doc.kind != JsonValue::Object) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf '" + file + "': top level must be an object");
+        auto arr = [&](const JsonValue& o, const char* key) -> const std::vector<JsonValue>& {
+            static const std::vector<JsonValue> empty;
+            const JsonValue* v = o.get(key);
+            return (v && v->kind == JsonValue::Array) ? v->arr : empty;
+        };
+        auto index_of = [&](const JsonValue& o, const char* key) -> int64_t {
+            const JsonValue* v = o.get(key);
+            return (v && v->kind == JsonValue::Int) ? v->i : -1;
+        };
+        // --- buffers
+        std::vector<std::vector<uint8_t>> buffers;
+        for (const JsonValue& b : arr(doc, "buffers")) {
+            const JsonValue* uri = b.get("uri");
+            if (uri && uri->kind == JsonValue::String) buffers.push_back(load_uri(uri->s, file));
+            else buffers.push_back(glb_bin);
+        }
+        const auto& views = arr(doc, "bufferViews");
+        const auto& accessors = arr(doc, "accessors");
+        struct Acc { const uint8_t* data; size_t count; int64_t comp; std::string type; size_t elem; };
+        // get_data_of_accessor (gltf.rs:448-460): the accessor's elements are read tightly packed
+        auto accessor = [&](int64_t ai, const std::string& what) -> Acc {
+            if (ai < 0 || (size_t)ai >= accessors.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: " + what + ": accessor index out of range");
+            const JsonValue& a = accessors[(size_t)ai];
+            int64_t vi = index_of(a, "bufferView");
+            if (vi < 0 || (size_t)vi >= views.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: Accessor has no buffer view");
+            const JsonValue& v = views[(size_t)vi];
+            int64_t bi = index_of(v, "buffer");
+            if (bi < 0 || (size_t)bi >= buffers.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: buffer index out of range");
+            Acc r;
+            r.count = (size_t)std::max<int64_t>(0, index_of(a, "count"));
+            r.comp = index_of(a, "componentType");
+            const JsonValue* ty = a.get("type");
+            r.type = (ty && ty->kind == JsonValue::String) ? ty->s : "";
+            size_t comps = r.type == "SCALAR" ? 1 : r.type == "VEC2" ? 2 : r.type == "VEC3" ? 3 : r.type == "VEC4" ? 4 : 0;
+            size_t csize = (r.comp == 5120 || r.comp == 5121) ? 1 : (r.comp == 5122 || r.comp == 5123) ? 2 : (r.comp == 5125 || r.comp == 5126) ? 4 : 0;
+            r.elem = comps * csize;
+            if (r.elem == 0) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: " + what + ": unsupported accessor type");
+            int64_t stride = index_of(v, "byteStride");
+            if (stride > 0 && (size_t)stride != r.elem)
+                throw HostError(SPT_HOST_ERR_UNSUPPORTED, "gltf: " + what + ": interleaved buffer views (byteStride) are not supported");
+            size_t voff = (size_t)std::max<int64_t>(0, index_of(v, "byteOffset")), vlen = (size_t)std::max<int64_t>(0, index_of(v, "byteLength"));
+            size_t aoff = (size_t)std::max<int64_t>(0, index_of(a, "byteOffset"));
+            const std::vector<uint8_t>& buf = buffers[(size_t)bi];
+            if (voff + vlen > buf.size() || aoff + r.count * r.elem > vlen) throw HostError(SPT_HOST_ERR_PARSE, "gltf: " + what + ": accessor exceeds its buffer view");
+            r.data = buf.data() + voff + aoff;
+            return r;
+        };
+        // --- images -> ImageTex "image_<i>" (load_images, gltf.rs:50-103)
+        std::vector<GltfTex> image_tex;
+        {
+            size_t i = 0;
+            for (const JsonValue& im : arr(doc, "images")) {
+                std::vector<uint8_t> bytes;
+                const JsonValue* uri = im.get("uri");
+                if (uri && uri->kind == JsonValue::String) {
+                    bytes = load_uri(uri->s, file);
+                } else {
+                    int64_t vi = index_of(im, "bufferView");
+                    if (vi < 0 || (size_t)vi >= views.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: image without uri or bufferView");
+                    const JsonValue& v = views[(size_t)vi];
+                    int64_t bi = index_of(v, "buffer");
+                    size_t off = (size_t)std::max<int64_t>(0, index_of(v, "byteOffset")), len = (size_t)std::max<int64_t>(0, index_of(v, "byteLength"));
+                    if (bi < 0 || (size_t)bi >= buffers.size() || off + len > buffers[(size_t)bi].size()) throw HostError(SPT_HOST_ERR_PARSE, "gltf: image buffer view out of range");
+                    bytes.assign(buffers[(size_t)bi].begin() + off, buffers[(size_t)bi].begin() + off + len);
+                }
+                uint32_t w = 0, h = 0;
+                std::vector<uint32_t> px;
+                decode_png_rgba8(bytes, file + "#image_" + std::to_string(i), &w, &h, &px);
+                uint32_t id = add_image_pixels(file + "#image_" + std::to_string(i), w, h, std::move(px));
+                GltfTex t;
+                t.node = add_tex_node(SPT_TEX_IMAGE);
+                hs.textures[t.node].image = id;
+                t.constant = false;
+                t.value = tex_average(t.node);   // the folded constants of an image-backed material hold the averages
+                t.alpha = 1.0f;
+                image_tex.push_back(t);
+                ++i;
+            }
+        }
+        const GltfTex scalar_one = gl_scalar({1, 1, 1});
+        // `image_{texture.index()}`: the reference looks the IMAGE up with the TEXTURE's index (gltf.rs:127,192,...)
+        auto image_of = [&](const JsonValue& mat_part, const char* key, bool* present) -> GltfTex {
+            const JsonValue* t = mat_part.get(key);
+            *present = t && t->kind == JsonValue::Object;
+            if (!*present) return scalar_one;
+            int64_t ti = index_of(*t, "index");
+            if (ti < 0 || (size_t)ti >= image_tex.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no texture named 'image_" + std::to_string(ti) + "'");
+            return image_tex[(size_t)ti];
+        };
+        // --- materials -> one Surface per glTF material (load_materials, gltf.rs:105-253)
+        std::vector<uint32_t> mat_surface;
+        for (const JsonValue& gm : arr(doc, "materials")) {
+            spt_material m;
+            std::memset(&m, 0, sizeof m);
+            spt_material_recipe r;
+            std::memset(&r, 0, sizeof r);
+            GltfTex t0, t1, trough;
+            const JsonValue* ext = gm.get("extensions");
+            const JsonValue* sg = (ext && ext->kind == JsonValue::Object) ? ext->get("KHR_materials_pbrSpecularGlossiness") : nullptr;
+            bool has;
+            if (sg && sg->kind == JsonValue::Object) {
+                float df[4] = {1, 1, 1, 1}, sf[3] = {1, 1, 1};
+                jvec(sg->get("diffuseFactor"), 4, df);
+                jvec(sg->get("specularFactor"), 3, sf);
+                const float gloss = (float)jnum(sg->get("glossinessFactor"), 1.0);
+                GltfTex dimg = image_of(*sg, "diffuseTexture", &has);
+                t0 = gl_scalar({df[0], df[1], df[2]});
+                if (has) t0 = gl_binary(SPT_TEX_MUL, t0, gl_srgb(dimg));
+                GltfTex simg = image_of(*sg, "specularGlossinessTexture", &has);
+                t1 = gl_scalar({sf[0], sf[1], sf[2]});
+                if (has) {
+                    t1 = gl_binary(SPT_TEX_MUL, t1, gl_srgb(simg));
+                    trough = gl_binary(SPT_TEX_SUB, scalar_one, gl_binary(SPT_TEX_MUL, gl_scalar({gloss, gloss, gloss}), simg));
+                    r.rough_chan = SPT_CHAN_A;
+                } else {
+                    trough = gl_scalar({1.0f - gloss, 1.0f - gloss, 1.0f - gloss});
+                    r.rough_chan = SPT_CHAN_R;
+                }
+                r.type = SPT_MAT_PBR_SPECULAR;
+                r.metal_chan = SPT_CHAN_R;
+                // pbr_specular.rs:60-92 at the constant values (only used when nothing is image-backed)
+                float rv = gl_chan(trough, r.rough_chan);
+                m.ax = m.ay = rv * rv;
+                m.c0[0] = t0.value.x; m.c0[1] = t0.value.y; m.c0[2] = t0.value.z;
+                m.c1[0] = t1.value.x; m.c1[1] = t1.value.y; m.c1[2] = t1.value.z;
+            } else {
+                static const JsonValue empty_obj = [] { JsonValue v; v.kind = JsonValue::Object; return v; }();
+                const JsonValue* pm = gm.get("pbrMetallicRoughness");
+                const JsonValue& mr = (pm && pm->kind == JsonValue::Object) ? *pm : empty_obj;
+                float bf[4] = {1, 1, 1, 1};
+                jvec(mr.get("baseColorFactor"), 4, bf);
+                const float mf = (float)jnum(mr.get("metallicFactor"), 1.0), rf = (float)jnum(mr.get("roughnessFactor"), 1.0);
+                GltfTex bimg = image_of(mr, "baseColorTexture", &has);
+                t0 = gl_scalar({bf[0], bf[1], bf[2]});
+                if (has) t0 = gl_binary(SPT_TEX_MUL, t0, gl_srgb(bimg));
+                GltfTex mimg = image_of(mr, "metallicRoughnessTexture", &has);
+                t1 = gl_scalar({mf, mf, mf});
+                trough = gl_scalar({rf, rf, rf});
+                if (has) {
+                    t1 = gl_binary(SPT_TEX_MUL, t1, mimg);
+                    trough = gl_binary(SPT_TEX_MUL, trough, mimg);
+                }
+                r.type = SPT_MAT_PBR_METALLIC;
+                r.rough_chan = SPT_CHAN_G;
+                r.metal_chan = SPT_CHAN_B;
+                // pbr_metallic.rs:75-104 at the constant values
+                float rv = gl_chan(trough, r.rough_chan), metallic = gl_chan(t1, r.metal_chan);
+                m.ax = m.ay = rv * rv;
+                V3 spec = t0.value * metallic + V3{0.04f, 0.04f, 0.04f} * (1.0f - metallic), diff = t0.value * (1.0f - metallic);
+                m.c0[0] = diff.x; m.c0[1] = diff.y; m.c0[2] = diff.z;
+                m.c1[0] = spec.x; m.c1[1] = spec.y; m.c1[2] = spec.z;
+            }
+            m.bxdf = (m.ax < 0.0001f || m.ay < 0.0001f) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+            m.fresnel = SPT_FRESNEL_SCHLICK;
+            m.substrate = SPT_SUBSTRATE_LAMBERT;
+            r.tex[0] = t0.node; r.tex[1] = t1.node; r.tex[2] = trough.node; r.tex[3] = trough.node;
+            if (!(t0.constant && t1.constant && trough.constant)) {
+                hs.material_recipes.push_back(r);
+                m.recipe = (uint32_t)hs.material_recipes.size();
+                any_textured = true;
+            }
+            hs.materials.push_back(m);
+            float em[3] = {0, 0, 0};
+            jvec(gm.get("emissiveFactor"), 3, em);
+            const JsonValue* ds = gm.get("doubleSided");
+            uint32_t si = add_surface((uint32_t)hs.materials.size() - 1, {em[0], em[1], em[2]}, ds && ds->kind == JsonValue::Bool && ds->b, -1);
+            GltfTex et = image_of(gm, "emissiveTexture", &has);
+            if (has) {
+                hs.surfaces[si].emissive_map = et.node + 1;
+                avg_emissive[si] = V3{em[0], em[1], em[2]} * tex_average(et.node);
+                any_textured = true;
+            }
+            GltfTex nt = image_of(gm, "normalTexture", &has);
+            if (has) { hs.surfaces[si].normal_map = nt.node + 1; any_textured = true; }
+            mat_surface.push_back(si);
+        }
+        // --- meshes -> one TriMesh per primitive (load_primitives, gltf.rs:255-343)
+        struct GPrim { PrimRec rec; int64_t material; };
+        std::vector<std::vector<GPrim>> mesh_prims;
+        std::vector<std::string> mesh_names;
+        {
+            size_t mi = 0;
+            for (const JsonValue& mesh : arr(doc, "meshes")) {
+                const JsonValue* nm = mesh.get("name");
+                std::string mesh_name = (nm && nm->kind == JsonValue::String) ? nm->s : "mesh_" + std::to_string(mi);
+                mesh_names.push_back(mesh_name);
+                std::vector<GPrim> prims_of;
+                size_t pi = 0;
+                for (const JsonValue& prim : arr(mesh, "primitives")) {
+                    const std::string prim_name = mesh_name + "_prim_" + std::to_string(pi);
+                    int64_t ia = index_of(prim, "indices");
+                    if (ia < 0) throw HostError(SPT_HOST_ERR_SCHEMA, "Primitives '" + prim_name + "' doesn't have indices");
+                    Acc idx = accessor(ia, prim_name + " indices");
+                    ObjMesh m;
+                    m.idx.assign(idx.count, 0u);
+                    if (idx.comp == 5125) { for (size_t k = 0; k < idx.count; ++k) std::memcpy(&m.idx[k], idx.data + 4 * k, 4); }
+                    else if (idx.comp == 5123) { for (size_t k = 0; k < idx.count; ++k) { uint16_t v; std::memcpy(&v, idx.data + 2 * k, 2); m.idx[k] = v; } }
+                    else throw HostError(SPT_HOST_ERR_UNSUPPORTED, "gltf: " + prim_name + ": only u16 / u32 indices are read (the reference leaves other types at 0)");
+                    const JsonValue* attrs = prim.get("attributes");
+                    if (!attrs || attrs->kind != JsonValue::Object || index_of(*attrs, "POSITION") < 0)
+                        throw HostError(SPT_HOST_ERR_SCHEMA, "Primitive '" + prim_name + "' doesn't have positions");
+                    Acc pos = accessor(index_of(*attrs, "POSITION"), prim_name + " POSITION");
+                    if (pos.comp != 5126 || pos.type != "VEC3") throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: " + prim_name + ": POSITION must be f32 VEC3");
+                    const size_t nv = pos.count;
+                    m.pos.resize(nv);
+                    // MeshVertex::default (triangle.rs:29-38)
+                    m.nrm.assign(nv, V3{0, 0, 1}); m.tan.assign(nv, V3{1, 0, 0}); m.bit.assign(nv, V3{0, 1, 0}); m.uv.assign(2 * nv, 0.0f);
+                    for (size_t k = 0; k < nv; ++k) std::memcpy(&m.pos[k], pos.data + 12 * k, 12);
+                    for (uint32_t v : m.idx) if (v >= nv) throw HostError(SPT_HOST_ERR_PARSE, "gltf: " + prim_name + ": vertex index out of range");
+                    int64_t ta = index_of(*attrs, "TEXCOORD_0");
+                    if (ta >= 0) {
+                        Acc uv = accessor(ta, prim_name + " TEXCOORD_0");
+                        if (uv.comp != 5126 || uv.type != "VEC2" || uv.count < nv) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "gltf: " + prim_name + ": TEXCOORD_0 must be f32 VEC2");
+                        std::memcpy(m.uv.data(), uv.data, 8 * nv);
+                    }
+                    int64_t na = index_of(*attrs, "NORMAL");
+                    if (na >= 0) {
+                        Acc nr = accessor(na, prim_name + " NORMAL");
+                        if (nr.comp != 5126 || nr.type != "VEC3" || nr.count < nv) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "gltf: " + prim_name + ": NORMAL must be f32 VEC3");
+                        for (size_t k = 0; k < nv; ++k) std::memcpy(&m.nrm[k], nr.data + 12 * k, 12);
+                    } else {
+                        calc_normals(m);
+                    }
+                    calc_tangents(m);
+                    GPrim g;
+                    g.rec.type = SPT_PRIM_MESH;
+                    g.rec.id = add_mesh(m, g.rec.box);
+                    g.material = index_of(prim, "material");
+                    prims_of.push_back(g);
+                    ++pi;
+                }
+                mesh_prims.push_back(std::move(prims_of));
+                ++mi;
+            }
+        }
+        // --- node hierarchy (parse_nodes, gltf.rs:345-446)
+        const auto& nodes = arr(doc, "nodes");
+        const auto& cams = arr(doc, "cameras");
+        const JsonValue* dext = doc.get("extensions");
+        const JsonValue* lext = (dext && dext->kind == JsonValue::Object) ? dext->get("KHR_lights_punctual") : nullptr;
+        static const std::vector<JsonValue> no_lights;
+        const std::vector<JsonValue>& glights = (lext && lext->kind == JsonValue::Object) ? arr(*lext, "lights") : no_lights;
+        std::function<void(int64_t, const M4&, int)> visit = [&](int64_t ni, const M4& parent, int depth) {
+            if (ni < 0 || (size_t)ni >= nodes.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: node index out of range");
+            if (depth > 256) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: node hierarchy too deep (cycle?)");
+            const JsonValue& node = nodes[(size_t)ni];
+            M4 local;
+            if (!jvec(node.get("matrix"), 16, local.m)) {
+                // Transform::Decomposed -> T * R * S (gltf crate, scene::Transform::matrix)
+                float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, sc[3] = {1, 1, 1};
+                jvec(node.get("translation"), 3, t);
+                jvec(node.get("rotation"), 4, q);
+                jvec(node.get("scale"), 3, sc);
+                const float x = q[0], y = q[1], z = q[2], w = q[3];
+                const float r[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
+                                    2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
+                                    2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};   // columns
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 3; ++k) local.m[4 * c + k] = r[3 * c + k] * sc[c];
+                local.m[12] = t[0]; local.m[13] = t[1]; local.m[14] = t[2];
+            }
+            const M4 trans = parent * local;
+            const V3 col1{trans.m[4], trans.m[5], trans.m[6]}, col2{trans.m[8], trans.m[9], trans.m[10]}, col3{trans.m[12], trans.m[13], trans.m[14]};
+            const JsonValue* nname = node.get("name");
+            const bool named = nname && nname->kind == JsonValue::String;
+            int64_t mi = index_of(node, "mesh");
+            if (mi >= 0) {
+                if ((size_t)mi >= mesh_prims.size()) throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: mesh index out of range");
+                Affine a;   // Affine3A::from_mat4
+                a.m.c0 = {trans.m[0], trans.m[1], trans.m[2]};
+                a.m.c1 = col1;
+                a.m.c2 = col2;
+                a.t = col3;
+                for (size_t k = 0; k < mesh_prims[(size_t)mi].size(); ++k) {
+                    const GPrim& g = mesh_prims[(size_t)mi][k];
+                    const std::string inst_name = mesh_names[(size_t)mi] + "_prim_" + std::to_string(k) + "_node_" + std::to_string(ni);
+                    if (g.material < 0 || (size_t)g.material >= mat_surface.size())
+                        throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: primitive '" + inst_name + "' has no material (the reference has no default material)");
+                    if (!instances.count(inst_name)) instances[inst_name] = make_instance(inst_name, a, g.rec, mat_surface[(size_t)g.material]);
+                }
+            }
+            int64_t ci = index_of(node, "camera");
+            if (ci >= 0 && (size_t)ci < cams.size()) {
+                const std::string cam_name = named ? nname->s : "camera_" + std::to_string(ni);
+                const JsonValue* ty = cams[(size_t)ci].get("type");
+                const JsonValue* persp = cams[(size_t)ci].get("perspective");
+                if (ty && ty->kind == JsonValue::String && ty->s == "perspective" && persp && persp->kind == JsonValue::Object) {
+                    if (!hs.camera_index.count(cam_name)) add_camera(cam_name, col3, -col2, col1, (float)jnum(persp->get("yfov"), 1.0));
+                } else {
+                    warn("Camera '" + cam_name + "' is orthographic and is not supported yet");
+                }
+            }
+            const JsonValue* next = node.get("extensions");
+            const JsonValue* nl = (next && next->kind == JsonValue::Object) ? next->get("KHR_lights_punctual") : nullptr;
+            int64_t li = (nl && nl->kind == JsonValue::Object) ? index_of(*nl, "light") : -1;
+            if (li >= 0 && (size_t)li < glights.size()) {
+                const JsonValue& gl = glights[(size_t)li];
+                const std::string light_name = named ? nname->s : "light_" + std::to_string(ni);
+                float color[3] = {1, 1, 1};
+                jvec(gl.get("color"), 3, color);
+                const float intensity = (float)jnum(gl.get("intensity"), 1.0);
+                spt_light l;
+                std::memset(&l, 0, sizeof l);
+                auto set3 = [](float* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+                set3(l.strength, V3{color[0], color[1], color[2]} * intensity);
+                const JsonValue* kind = gl.get("type");
+                const std::string k = (kind && kind->kind == JsonValue::String) ? kind->s : "";
+                if (k == "directional") {
+                    l.type = SPT_LIGHT_DIRECTIONAL;
+                    set3(l.dir, normalize(-col2));   // DirLight::new normalises
+                } else if (k == "point") {
+                    l.type = SPT_LIGHT_POINT;
+                    set3(l.pos, col3);
+                } else if (k == "spot") {
+                    l.type = SPT_LIGHT_SPOT;
+                    set3(l.pos, col3);
+                    set3(l.dir, -col2);              // SpotLight::new keeps the direction as it is
+                    const JsonValue* spot = gl.get("spot");
+                    l.cos_inner = std::cos((float)jnum(spot ? spot->get("innerConeAngle") : nullptr, 0.0));
+                    l.cos_outer = std::cos((float)jnum(spot ? spot->get("outerConeAngle") : nullptr, 0.7853981633974483));
+                } else {
+                    throw HostError(SPT_HOST_ERR_SCHEMA, "gltf: light '" + light_name + "': unknown type '" + k + "'");
+                }
+                l.power = luminance({l.strength[0], l.strength[1], l.strength[2]});
+                if (!lights.count(light_name)) lights[light_name] = l;
+            }
+            for (const JsonValue& ch : arr(node, "children"))
+                if (ch.kind == JsonValue::Int) visit(ch.i, trans, depth + 1);
+        };
+        for (const JsonValue& scn : arr(doc, "scenes"))
+            for (const JsonValue& root : arr(scn, "nodes"))
+                if (root.kind == JsonValue::Int) visit(root.i, M4(), 0);
+    }
+
     float instance_area(const InstRec& r) {
         const spt_instance& in = r.inst;
         if (in.prim_type == SPT_PRIM_SPHERE) {
@@ -1124,8 +1592,19 @@ void HostScene::finalize_desc() {
 
 // loader::load_scene (src/loader/json.rs:53-199): fixed section order
 HostScene* load_scene_file(const std::string& path) {
+    // loader::load_scene (src/loader/mod.rs:20-31): by file extension
+    const bool is_gltf = (path.size() >= 5 && path.substr(path.size() - 5) == ".gltf") || (path.size() >= 4 && path.substr(path.size() - 4) == ".glb");
+    if (is_gltf) {   // gltf::load_scene (gltf.rs:13-17): to_scene(None, None) = bvh aggregate, uniform light sampler
+        std::unique_ptr<HostScene> hs(new HostScene());
+        SceneBuilder b(*hs, path);
+        b.import_gltf(path);
+        JsonValue none;
+        none.kind = JsonValue::Object;
+        b.finish(none);
+        return hs.release();
+    }
     if (path.size() < 5 || path.substr(path.size() - 5) != ".json")
-        throw HostError(SPT_HOST_ERR_SCHEMA, "File extension is not recognized (only .json scenes are in scope)");
+        throw HostError(SPT_HOST_ERR_SCHEMA, "File extension is not recognized");
     JsonValue root = parse_json_file(path);
     if (root.kind != JsonValue::Object) throw HostError(SPT_HOST_ERR_SCHEMA, "scene - top level must be an object");
     std::unique_ptr<HostScene> hs(new HostScene());
@@ -1147,7 +1626,10 @@ HostScene* load_scene_file(const std::string& path) {
         b.load_section(*v, s.env, s.fn, true);
     }
     if (const JsonValue* v = root.get("environment")) b.load_section(*v, "json-environment", &SceneBuilder::load_env, false);
-    if (root.get("gltf")) throw HostError(SPT_HOST_ERR_UNSUPPORTED, "scene - 'gltf' import is outside the hot-path scope (SURVEY 2 #20)");
+    if (const JsonValue* g = root.get("gltf")) {   // json.rs:168-175: merged after the JSON sections
+        if (g->kind != JsonValue::String) throw HostError(SPT_HOST_ERR_SCHEMA, "json - 'gltf' should be string");
+        b.import_gltf(with_file_name(path, g->s));
+    }
     b.finish(root);
     return hs.release();
 }

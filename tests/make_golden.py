@@ -19,6 +19,7 @@ CASES = [  # name, scene, camera, sampler, spp, (w, h), seed
     ("film_t_medium", "t_medium.json", None, "random", 16, (64, 48), 1),
     ("film_t_plastic", "t_plastic.json", None, "random", 16, (64, 48), 1),
     ("film_t_textured", "t_textured.json", None, "recurrence", 16, (64, 48), 1),
+    ("film_t_gltf", "t_gltf.gltf", "cam", "random", 16, (64, 48), 1),
 ]
 
 

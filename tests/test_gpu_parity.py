@@ -26,7 +26,7 @@ def _scene(spt, name):
     return spt.load_scene(os.path.join(_util.SCENES, name))
 
 
-@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json"])
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json", "t_gltf.gltf"])
 def test_trace_closest_and_any_bit_exact(spt, scene_name):
     sc = _scene(spt, scene_name)
     rays = _util.random_rays(sc, 200_000, seed=11)
@@ -91,6 +91,7 @@ def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
     ("t_plastic.json", None, "random"),          # plastic (rough/smooth/aniso), pbr_metallic, pbr_specular
     ("t_textured.json", None, "random"),         # image textures: mips + trilinear (camera-ray differentials), wrap / tiling /
     ("t_textured.json", None, "recurrence"),     #   mode, sRGB, binary ops, normal + emissive maps, per-hit material recipes
+    ("t_gltf.gltf", "cam", "random"),            # glTF import: metallic-roughness (G / B channels), spec-gloss (alpha), punctual lights
 ])
 def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     sc = _scene(spt, scene_name)
