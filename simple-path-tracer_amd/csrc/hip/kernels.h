@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             DInter it;
             it.prim_type = 0u; it.prim_id = 0u;
             if (does_hit) {
-                it = reconstruct_hit<kTex>(sc, ray, h);
+                it = reconstruct_hit<kTex, kFused>(sc, ray, h);
                 if (kTex && kFirst) calc_differential(it, ray, h.t, rc.cam.eye, aux_xd, rc.cam.eye, aux_yd);   // pt.rs:51-53
             }
 
@@ -455,9 +455,9 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     }
                     alive = false;
                 } else {  // pt.rs:112-193
-                    const spt_surface& sf = sc.surfaces[it.surface];
+                    const spt_surface sf = load_surface<kFused>(sc, it.surface);
                     const uint32_t sflags = sf.flags;
-                    DMat mt = material_at<kTex>(sc, sf.material, it);
+                    DMat mt = material_at<kTex, kFused>(sc, sf.material, it);
                     if (kSimple) mt.bxdf = SPT_BXDF_LAMBERT;
                     DCoord coord = surface_coord<kTex>(sc, sf, ray, it);
                     f3 po = it.position;
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     lsi = po;
                     if (!mat_is_delta(mt)) {
                         DLightSample ls;
-                        if (sample_light<kSimple, kTex>(sc, lsi, rng, &ls)) {
+                        if (sample_light<kSimple, kTex, kFused>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
                             f3 f = mat_eval(mt, wo, wi);
                             float mpdf = mat_pdf(mt, wo, wi);

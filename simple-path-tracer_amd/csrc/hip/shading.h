@@ -43,17 +43,50 @@ SPT_DEV void sphere_frame(f3 norm, f3* tangent, f3* bitangent) {  // sphere.rs:7
     }
 }
 
+// Shading-table fetch.  kL (the fused shade kernel of an LDS-resident scene): instances, triangle attributes,
+// surfaces, materials and lights were staged into LDS behind the traversal geometry, so the dependent chain
+// hit -> instance -> attributes -> surface -> material -> light costs LDS instead of L2 latency.
+template <bool kL>
+SPT_DEV float4 tab_ld(const DScene& sc, const float4* global, uint32_t lds_off, uint32_t i) {
+    if (kL) return geo_lds(sc)[lds_off + i];
+    return global[i];
+}
+template <bool kL>
+SPT_DEV spt_surface load_surface(const DScene& sc, uint32_t i) {
+    const float4* g = reinterpret_cast<const float4*>(sc.surfaces);
+    const float4 a = tab_ld<kL>(sc, g, sc.o_surf, 2u * i), b = tab_ld<kL>(sc, g, sc.o_surf, 2u * i + 1u);
+    spt_surface s;
+    s.material = __float_as_uint(a.x); s.flags = __float_as_uint(a.y); s.inside_medium = __float_as_int(a.z);
+    s.emissive[0] = a.w; s.emissive[1] = b.x; s.emissive[2] = b.y;
+    s.normal_map = __float_as_uint(b.z); s.emissive_map = __float_as_uint(b.w);
+    return s;
+}
+template <bool kL>
+SPT_DEV spt_light load_light(const DScene& sc, uint32_t i) {
+    const float4* g = reinterpret_cast<const float4*>(sc.lights);
+    const float4 a = tab_ld<kL>(sc, g, sc.o_light, 4u * i), b = tab_ld<kL>(sc, g, sc.o_light, 4u * i + 1u),
+                 c = tab_ld<kL>(sc, g, sc.o_light, 4u * i + 2u), d = tab_ld<kL>(sc, g, sc.o_light, 4u * i + 3u);
+    spt_light l;
+    l.type = __float_as_uint(a.x);
+    l.pos[0] = a.y; l.pos[1] = a.z; l.pos[2] = a.w;
+    l.dir[0] = b.x; l.dir[1] = b.y; l.dir[2] = b.z;
+    l.strength[0] = b.w; l.strength[1] = c.x; l.strength[2] = c.y;
+    l.cos_inner = c.z; l.cos_outer = c.w;
+    l.instance = __float_as_uint(d.x); l.power = d.y; l.pad[0] = 0.0f; l.pad[1] = 0.0f;
+    return l;
+}
+
 struct DInstance {
     float inv[12], fwd[12], nrm[9];
     uint32_t prim_type, prim_id, surface;
     int32_t light;
 };
+template <bool kL = false>
 SPT_DEV DInstance load_instance(const DScene& sc, uint32_t inst) {
-    const float4* I = sc.instances + 12 * inst;
     DInstance d;
     float4 q[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) q[k] = I[k];
+    for (int k = 0; k < 10; ++k) q[k] = tab_ld<kL>(sc, sc.instances, sc.o_inst, 12u * inst + (uint32_t)k);
     const float* w = reinterpret_cast<const float*>(q);
 #pragma unroll
     for (int k = 0; k < 12; ++k) d.inv[k] = w[k];
@@ -77,9 +110,9 @@ SPT_DEV void sphere_normal_to_texcoords(f3 p, float* uv) {  // sphere.rs:138-145
 
 // Rebuild the shading inputs of a recorded hit (t, instance, prim, v, w):
 // triangle.rs:188-212 or sphere.rs:64-83, then instance.rs:97-104.  kTex: also the texcoords.
-template <bool kTex = false>
+template <bool kTex = false, bool kL = false>
 SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h) {
-    const DInstance in = load_instance(sc, (uint32_t)h.inst);
+    const DInstance in = load_instance<kL>(sc, (uint32_t)h.inst);
     DInter it;
     f3 n, tg, bt;
     it.uv[0] = 0.0f; it.uv[1] = 0.0f;
@@ -88,15 +121,14 @@ SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h)
         DRay orr;
         orr.o = xf_point(in.inv, ray.o);
         orr.d = xf_vector(in.inv, ray.d);
-        float4 s = sc.spheres[in.prim_id];
+        float4 s = tab_ld<kL>(sc, sc.spheres, sc.o_sph, in.prim_id);
         n = (point_at(orr, h.t) - mk3(s)) / s.w;
         sphere_frame(n, &tg, &bt);
         if (kTex) sphere_normal_to_texcoords(n, it.uv);
     } else {
-        const float4* A = sc.tri_attr + 9 * (uint32_t)h.prim;
         float4 q[kTex ? 9 : 7];
 #pragma unroll
-        for (int k = 0; k < (kTex ? 9 : 7); ++k) q[k] = A[k];
+        for (int k = 0; k < (kTex ? 9 : 7); ++k) q[k] = tab_ld<kL>(sc, sc.tri_attr, sc.o_attr, 9u * (uint32_t)h.prim + (uint32_t)k);
         const float* a = reinterpret_cast<const float*>(q);  // n[3][3] t[3][3] b[3][3] uv[3][2]
         float v = h.v, w = h.w;
         float u = 1.0f - v - w;
@@ -446,9 +478,11 @@ struct DMat {
     float ax, ay, ior;
     uint32_t fresnel, substrate;
 };
+template <bool kL = false>
 SPT_DEV DMat load_material(const DScene& sc, uint32_t m) {
-    const float4* p = reinterpret_cast<const float4*>(sc.materials + m);   // 64-byte records
-    float4 a = p[0], b = p[1], c = p[2], e = p[3];
+    const float4* p = reinterpret_cast<const float4*>(sc.materials);   // 64-byte records
+    float4 a = tab_ld<kL>(sc, p, sc.o_mat, 4u * m), b = tab_ld<kL>(sc, p, sc.o_mat, 4u * m + 1u), c = tab_ld<kL>(sc, p, sc.o_mat, 4u * m + 2u),
+           e = tab_ld<kL>(sc, p, sc.o_mat, 4u * m + 3u);
     DMat d;
     d.bxdf = __float_as_uint(a.x);
     d.c0 = mk3(a.y, a.z, a.w);
@@ -468,9 +502,9 @@ SPT_DEV float fresnel_moment1(float eta) {  // src/bxdf/util.rs:123-134
 }
 // MaterialT::bxdf_context at a hit (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs):
 // constant materials were folded by the loader; a material with an image-backed parameter carries a recipe.
-template <bool kTex>
+template <bool kTex, bool kL = false>
 SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
-    DMat d = load_material(sc, m);
+    DMat d = load_material<kL>(sc, m);
     if (!kTex) return d;
     const uint32_t recipe = __float_as_uint(reinterpret_cast<const float4*>(sc.materials + m)[3].w);
     if (recipe == 0u) return d;
@@ -1024,19 +1058,19 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
 }
 
 // sample_light (uniform.rs:28-41, power_is.rs:49-59); false if the scene has no light
-template <bool kDeltaOnly, bool kTex = false>
+template <bool kDeltaOnly, bool kTex = false, bool kL = false>
 SPT_DEV bool sample_light(const DScene& sc, f3 position, DRng& rng, DLightSample* out) {
     if (sc.n_lights == 0) return false;
     if (sc.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) {
         float pr;
         uint32_t index = alias_sample(sc.light_props, sc.light_u, sc.light_k, sc.n_lights, rng.next(), &pr);
-        light_sample<kDeltaOnly, kTex>(sc, sc.lights[index], position, rng, out);
+        light_sample<kDeltaOnly, kTex>(sc, load_light<kL>(sc, index), position, rng, out);
         out->pdf = pr * out->pdf;
     } else {
         float fi = rng.next() * (float)sc.n_lights;
         uint32_t index = spt_f2u_sat(fi);
         if (index > sc.n_lights - 1) index = sc.n_lights - 1;
-        light_sample<kDeltaOnly, kTex>(sc, sc.lights[index], position, rng, out);
+        light_sample<kDeltaOnly, kTex>(sc, load_light<kL>(sc, index), position, rng, out);
         out->pdf = out->pdf * (1.0f / (float)sc.n_lights);
     }
     return true;

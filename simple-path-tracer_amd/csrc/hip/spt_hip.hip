@@ -440,6 +440,7 @@ struct spt_scene {
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     bool bs_valid = false;
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
+    bool fused = false;     // k_shade<0, ., kFused> can run: geometry AND shading tables staged in LDS
     bool textured = false;  // a material recipe, normal map or emissive map samples textures per hit (k_shade<2, .>)
     DeviceBuffer textures, tex_prog, tex_root, tex_chain, images, image_levels, texels, recipes;
     std::vector<hipEvent_t> events;
@@ -745,6 +746,27 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             sc->lds_geo = blob.size() * 16 <= 32u * 1024u && stack_bytes + blob.size() * 16 <= 64u * 1024u;
             if (std::getenv("SPT_NO_LDS_GEO")) sc->lds_geo = false;   // tests: drive small scenes through the large-scene path
             if (!sc->lds_geo) assemble(true);
+            // fused bounces (k_shade<0, ., kFused>): LDS-resident geometry + the lean simple-scene shade kernel, and
+            // the shading tables must fit behind the geometry too (see tab_ld in shading.h)
+            {
+                bool simple_scene = s.env.width == 0 && s.n_lights > 0;
+                for (uint32_t i = 0; i < s.n_materials; ++i) simple_scene = simple_scene && s.materials[i].bxdf == SPT_BXDF_LAMBERT && s.materials[i].recipe == 0;
+                for (uint32_t i = 0; i < s.n_lights; ++i) simple_scene = simple_scene && s.lights[i].type <= SPT_LIGHT_SPOT;
+                for (uint32_t i = 0; i < s.n_surfaces; ++i) {
+                    const spt_surface& sf = s.surfaces[i];
+                    float lum = 0.299f * sf.emissive[0] + 0.587f * sf.emissive[1] + 0.114f * sf.emissive[2];
+                    simple_scene = simple_scene && sf.inside_medium < 0 && !(lum > 0.0f) && sf.normal_map == 0 && sf.emissive_map == 0;
+                }
+                const size_t extra = (size_t)s.n_tris * sizeof(spt_tri_attr) + (size_t)s.n_surfaces * sizeof(spt_surface) +
+                                     (size_t)s.n_materials * sizeof(spt_material) + (size_t)s.n_lights * sizeof(spt_light) + 64;
+                sc->fused = sc->lds_geo && simple_scene && blob.size() * 16 + extra <= 32u * 1024u && stack_bytes + blob.size() * 16 + extra <= 64u * 1024u;
+                if (sc->fused) {
+                    d.o_attr = append(s.tri_attr, (size_t)s.n_tris * sizeof(spt_tri_attr));
+                    d.o_surf = append(s.surfaces, (size_t)s.n_surfaces * sizeof(spt_surface));
+                    d.o_mat = append(s.materials, (size_t)s.n_materials * sizeof(spt_material));
+                    d.o_light = append(s.lights, (size_t)s.n_lights * sizeof(spt_light));
+                }
+            }
             if (blob.size() > 0x7fffffffull / 16) fail(SPT_ERR_UNSUPPORTED, "scene geometry larger than 32 GiB");
             sc->geo.upload(blob.data(), blob.size());
             d.geo = sc->geo.as<float4>();
@@ -934,7 +956,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         sc->hit_inst.ensure(cap * 4);
         // see k_shade<.., kFused>.  Only the lean k_shade<0> variant gains: with the general kernel's 220+ VGPRs
         // the two traversals run at 2 waves / SIMD and cfg4 is faster un-fused (4.30 vs 4.00 Gsamples/s, measured)
-        const bool fused = sc->lds_geo && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
+        const bool fused = sc->fused && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
         if (fused) {
             sc->hit_f4_next.ensure(cap * 16);
             sc->hit_inst_next.ensure(cap * 4);

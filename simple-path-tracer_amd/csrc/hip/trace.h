@@ -48,6 +48,8 @@ struct DScene {
     uint32_t geo_f4;           // blob length in float4
     uint32_t lds_f4;           // staged prefix length in float4 (== geo_f4 for k_*<true>)
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
+    // fused bounces only: the shading tables also sit in the staged blob (float4 offsets), see tab_ld
+    uint32_t o_attr, o_surf, o_mat, o_light;
     uint32_t fast_slab;        // device-built (padded) trees: box tests only cull, so 1/d may be v_rcp_f32 (1 ulp)
     uint32_t tlas_root;        // ref of the TLAS root (wide-node index or leaf ref)
     float tlas_lo[3], tlas_hi[3];  // its box
