@@ -245,8 +245,9 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
             if (first == rc.pass_samples) first = s;
             rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
         }
-        // (deferring this append by one iteration to overlap the atomic with the next sample was
-        //  MEASURED slower: +16 VGPRs of pending state drop the kernel from 4 to 3 waves per SIMD)
+        // (deferring this append by one iteration to overlap the counter atomic with the next sample was tried
+        //  twice: at 120 VGPRs the pending state cost a wave per SIMD and it was slower, at 104 VGPRs it fits
+        //  but MEASURED the same 2.70 ms - the atomic is not what the kernel waits for)
         const uint32_t slot = shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {
             // bounce-0 records are compact: origin (eye), t_min, throughput (1), last_pdf (0), depth, medium and
@@ -297,9 +298,25 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
     uint32_t* ext_count = q_count(rc.counts, bounce, Q_EXT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
-    for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+    // fused bounce 0: the hit record of the NEXT iteration is requested before this iteration's shading and
+    // traversals, so its HBM latency is hidden behind them (3 waves / SIMD cannot hide it otherwise)
+    constexpr bool kPrefetch = kFused && kFirst;
+    float4 pre_hv = make_float4(0, 0, 0, 0), pre_b = make_float4(0, 0, 0, 0);
+    int32_t pre_inst = -1;
+    const uint32_t i_first = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u);
+    if (kPrefetch && i_first + lane_id() < n) {
+        const uint32_t k = qbase + i_first + lane_id();
+        pre_hv = rc.hits.t_v_w_prim[k]; pre_b = rc.qa.d_pdf[k]; pre_inst = rc.hits.inst[k];
+    }
+    for (uint32_t i0 = i_first; i0 < n; i0 += stride) {
         const bool active = i0 + lane_id() < n;
         const uint32_t idx = qbase + i0 + lane_id();
+        const float4 cur_hv = pre_hv, cur_b = pre_b;
+        const int32_t cur_inst = pre_inst;
+        if (kPrefetch && i0 + stride + lane_id() < n) {
+            const uint32_t k = idx + stride;
+            pre_hv = rc.hits.t_v_w_prim[k]; pre_b = rc.qa.d_pdf[k]; pre_inst = rc.hits.inst[k];
+        }
         bool want_shadow = false, want_ext = false;
         DRay shadow_ray, next_ray;
         float shadow_tmax = 0.0f, next_pdf = 0.0f;
@@ -309,13 +326,13 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
         DRng rng;
         rng.s.state = 0ull;
         if (active) {
-            float4 hv = rc.hits.t_v_w_prim[idx];
+            float4 hv = kPrefetch ? cur_hv : rc.hits.t_v_w_prim[idx];
             DRay ray;
             float last_pdf;
             f3 aux_xd = mk3(0, 0, 0), aux_yd = mk3(0, 0, 0);
             if (kFirst) {
                 // rebuild the constants of a camera path from the slot (see k_primary)
-                const float4 b = rc.qa.d_pdf[idx];
+                const float4 b = kPrefetch ? cur_b : rc.qa.d_pdf[idx];
                 slot = __float_as_uint(b.w);
                 const uint32_t s_local = slot / rc.n_pixels, lp = slot - s_local * rc.n_pixels;
                 const uint32_t row_local = lp / rc.width, col = lp - row_local * rc.width;
@@ -358,7 +375,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             }
             DHit h;
             h.t = hv.x; h.v = hv.y; h.w = hv.z; h.prim = __float_as_int(hv.w);
-            h.inst = rc.hits.inst[idx];
+            h.inst = kPrefetch ? cur_inst : rc.hits.inst[idx];
             const bool does_hit = h.inst >= 0;
             bool alive = true;       // false: path ended without the RR / depth tail (`break`)
             bool scattered = false;  // a new ray was produced (tail applies)
