@@ -79,6 +79,9 @@ struct RenderCtx {
     f3 bs_oc;                 // sphere centre - eye
     float bs_c;               // |oc|^2 - R^2   (R inflated by 0.1 %)
     uint32_t bs_valid;
+    // screen-space bound of the scene: pixels outside [cull_i0, cull_i1] x [cull_j0, cull_j1] (image coordinates,
+    // one pixel of slack) cannot see any instance box; the full image when the bound is not available
+    int32_t cull_i0, cull_i1, cull_j0, cull_j1;
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
 };
 
@@ -197,7 +200,12 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     uint32_t first = rc.pass_samples;
     const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
     uint32_t* hit_counter = q_count(rc.counts, 0, Q_HIT, shard);
-    for (uint32_t s = 0; s < rc.pass_samples; ++s) {
+    // A pixel whose whole footprint lies outside the projected bounds of the scene cannot hit anything with any
+    // of its samples.  Without an environment all of them are black and leave no trace (film += 0, no radiance
+    // slot), so the sample loop is not entered; with one they still look the environment up, but skip the trace.
+    const bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
+    const uint32_t n_loop = (in_bounds || has_env) ? rc.pass_samples : 0u;
+    for (uint32_t s = 0; s < n_loop; ++s) {
         const uint32_t gs = rc.pass_first + s;
         DRng rng;
         rng.s.state = 0ull;
@@ -211,8 +219,8 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
         // normalisation and the traversal: nothing can be hit, and without an environment the sample
         // is black.  The sphere is inflated, so the test only removes rays every box test would reject.
         const f3 du = (rc.cam.forward * rc.cam.half_cot + rc.cam.right * x) + rc.cam.up * y;
-        bool may_hit = valid;
-        if (rc.bs_valid && rc.bs_c > 0.0f) {
+        bool may_hit = valid && in_bounds;
+        if (may_hit && rc.bs_valid && rc.bs_c > 0.0f) {
             const float b = dot(du, rc.bs_oc);
             may_hit = valid && (b > 0.0f) && (b * b >= dot(du, du) * rc.bs_c);
         }

@@ -438,6 +438,7 @@ struct spt_scene {
     DeviceBuffer trace_in, trace_out;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
+    double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
     bool bs_valid = false;
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
     bool fused = false;     // k_shade<0, ., kFused> can run: geometry AND shading tables staged in LDS
@@ -869,6 +870,8 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             double r2 = 0;
             for (int k = 0; k < 3; ++k) {
                 sc->bs_center[k] = 0.5 * (lo[k] + hi[k]);
+                sc->world_lo[k] = lo[k];
+                sc->world_hi[k] = hi[k];
                 r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]);
             }
             sc->bs_radius = std::sqrt(r2) * 1.001 + 1e-4;
@@ -1009,6 +1012,39 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             // a little extra slack for the f32 rounding of oc and of the test itself
             rc.bs_c = (float)((d2 - sc->bs_radius * sc->bs_radius) * (1.0 - 1e-5));
             rc.bs_valid = sc->bs_valid ? 1u : 0u;
+            // screen-space bound: project the 8 corners of the union of the instance boxes (double precision).
+            // A point P is seen through image coordinates (u, v) = ((x / aspect + 0.5) W, (y + 0.5) H) with
+            // x = half_cot * (P - eye).right / (P - eye).forward, y likewise with up (k_primary: pt.rs:269-271).
+            rc.cull_i0 = 0; rc.cull_i1 = (int32_t)p.width - 1; rc.cull_j0 = 0; rc.cull_j1 = (int32_t)p.height - 1;
+            if (sc->bs_valid && std::getenv("SPT_NO_PIXEL_CULL") == nullptr) {
+                double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+                bool ok = true;
+                const double ext = std::max({sc->world_hi[0] - sc->world_lo[0], sc->world_hi[1] - sc->world_lo[1], sc->world_hi[2] - sc->world_lo[2], 1e-30});
+                for (int c = 0; c < 8 && ok; ++c) {
+                    double v[3], z = 0, xr = 0, yu = 0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double pad = 1e-4 * ext;   // covers the (tiny) padding of the device-side boxes
+                        v[k] = (((c >> k) & 1) ? sc->world_hi[k] + pad : sc->world_lo[k] - pad) - (double)cam->eye[k];
+                        z += v[k] * (double)cam->forward[k];
+                        xr += v[k] * (double)cam->right[k];
+                        yu += v[k] * (double)cam->up[k];
+                    }
+                    if (!(z > 1e-6 * ext)) { ok = false; break; }   // a corner beside / behind the eye: no finite bound
+                    const double x = (double)cam->half_cot_half_fov * xr / z, y = (double)cam->half_cot_half_fov * yu / z;
+                    const double u = (x / ((double)p.width / (double)p.height) + 0.5) * (double)p.width, w = (y + 0.5) * (double)p.height;
+                    umin = std::min(umin, u); umax = std::max(umax, u);
+                    vmin = std::min(vmin, w); vmax = std::max(vmax, w);
+                }
+                if (ok && std::isfinite(umin) && std::isfinite(umax) && std::isfinite(vmin) && std::isfinite(vmax)) {
+                    // pixel i covers u in [i, i + 1); row j covers v in [H - 1 - j, H - j); one pixel of slack each side
+                    const double H = (double)p.height;
+                    auto clampi = [](double x, double lo, double hi) { return (int32_t)std::max(lo, std::min(hi, x)); };
+                    rc.cull_i0 = clampi(std::floor(umin) - 1.0, -1.0, (double)p.width);
+                    rc.cull_i1 = clampi(std::floor(umax) + 1.0, -1.0, (double)p.width);
+                    rc.cull_j0 = clampi(std::floor(H - 1.0 - vmax) - 1.0, -1.0, H);
+                    rc.cull_j1 = clampi(std::floor(H - 1.0 - vmin) + 2.0, -1.0, H);
+                }
+            }
         }
 
         hipStream_t st = sc->stream;
