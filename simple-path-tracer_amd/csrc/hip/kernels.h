@@ -82,6 +82,7 @@ struct RenderCtx {
     // screen-space bound of the scene: pixels outside [cull_i0, cull_i1] x [cull_j0, cull_j1] (image coordinates,
     // one pixel of slack) cannot see any instance box; the full image when the bound is not available
     int32_t cull_i0, cull_i1, cull_j0, cull_j1;
+    uint32_t n_tiles, primary_chunks, chunk_samples;   // k_primary<., kChunked>: tiles of the shard, chunks per tile, samples per chunk
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
 };
 
@@ -181,10 +182,18 @@ SPT_DEV void store_path(const PathQueue& q, uint32_t i, const DRay& ray, float l
 constexpr uint32_t kTile = 16;
 SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % kShards; }
 
-template <bool kLds>
+// kChunked: the samples of the pass are split over rc.primary_chunks workgroups per tile (blockIdx = tile +
+// n_tiles * chunk).  Needed when the shard has few (active) tiles - a rank of an 8-GPU run owns 1/8 of the rows,
+// and only the tiles inside the screen-space bound do work - or the sample loops of a few hundred workgroups
+// would run on an otherwise idle chip.  A chunk cannot know whether an earlier sample of its pixel hit, so here
+// EVERY sample of a live pixel owns a radiance slot (first_slot = 0) and the film is only touched by k_resolve,
+// which adds the slots in sample order: the same additions in the same order as the register sum of the
+// un-chunked kernel (a miss adds exactly +0 or its environment term), so the film is bit-identical.
+template <bool kLds, bool kChunked = false>
 __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     stage_geometry<kLds>(sc);
-    const uint32_t tx = blockIdx.x % rc.tiles_x, ty = blockIdx.x / rc.tiles_x;
+    const uint32_t tile = kChunked ? blockIdx.x % rc.n_tiles : blockIdx.x, chunk = kChunked ? blockIdx.x / rc.n_tiles : 0u;
+    const uint32_t tx = tile % rc.tiles_x, ty = tile / rc.tiles_x;
     const uint32_t i = tx * kTile + (threadIdx.x % kTile);
     const uint32_t row_local = ty * kTile + (threadIdx.x / kTile);
     const bool valid = (i < rc.width) && (row_local < rc.rows);
@@ -196,16 +205,18 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     const bool lazy_rng = rc.sampler == SPT_SAMPLER_RECURRENCE;  // the R2 sampler draws nothing: seed hits only
     const uint32_t shard = tile_shard(tx, ty);
     f3 sum = mk3(0, 0, 0);
-    if (valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
-    uint32_t first = rc.pass_samples;
+    if (!kChunked && valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+    uint32_t first = kChunked ? 0u : rc.pass_samples;
     const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
     uint32_t* hit_counter = q_count(rc.counts, 0, Q_HIT, shard);
     // A pixel whose whole footprint lies outside the projected bounds of the scene cannot hit anything with any
     // of its samples.  Without an environment all of them are black and leave no trace (film += 0, no radiance
     // slot), so the sample loop is not entered; with one they still look the environment up, but skip the trace.
     const bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
-    const uint32_t n_loop = (in_bounds || has_env) ? rc.pass_samples : 0u;
-    for (uint32_t s = 0; s < n_loop; ++s) {
+    const bool live = in_bounds || has_env;
+    const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
+    const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
+    for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t gs = rc.pass_first + s;
         DRng rng;
         rng.s.state = 0ull;
@@ -266,7 +277,9 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
             rc.hits.inst[slot] = h.inst;
         }
     }
-    if (valid) {
+    if (kChunked) {
+        if (valid && chunk == 0u) rc.first_slot[lp] = live ? 0u : rc.pass_samples;
+    } else if (valid) {
         rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
         rc.first_slot[lp] = first;
     }

@@ -1080,6 +1080,22 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             HIP_CHECK(hipEventRecord(get_event(), st));
         };
         hipEvent_t ev_total0 = get_event(), ev_total1 = get_event();
+        // tiles of this shard that intersect the screen-space bound (all of them with an environment)
+        uint32_t active_tiles = pix_blocks;
+        if (sc->d.env_w == 0u) {
+            active_tiles = 0;
+            for (uint32_t ty = 0; ty < tiles_y; ++ty)
+                for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+                    const int32_t i_lo = (int32_t)(tx * kTile), i_hi = (int32_t)std::min(p.width, (tx + 1) * kTile) - 1;
+                    bool rows_in = false;
+                    for (uint32_t r = ty * kTile; r < std::min(rows, (ty + 1) * kTile) && !rows_in; ++r) {
+                        const uint32_t strip = r / strip_rows;
+                        const int32_t j = (int32_t)((strip * shard_count + p.shard_index) * strip_rows + (r - strip * strip_rows));
+                        rows_in = j >= rc.cull_j0 && j <= rc.cull_j1;
+                    }
+                    if (rows_in && i_hi >= rc.cull_i0 && i_lo <= rc.cull_i1) ++active_tiles;
+                }
+        }
         HIP_CHECK(hipEventRecord(ev_total0, st));
         HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
         std::vector<uint32_t> h_counts;
@@ -1091,8 +1107,23 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             HIP_CHECK(hipMemsetAsync(rc.counts, 0, counts_bytes, st));
             end();
             begin(SPT_K_PRIMARY);
-            if (L) hipLaunchKernelGGL(k_primary<true>, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
-            else hipLaunchKernelGGL(k_primary<false>, dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+            // sample chunks per tile: aim at ~4096 busy workgroups (16 per CU) given the tiles inside the screen bound
+            rc.n_tiles = pix_blocks;
+            rc.primary_chunks = 1;
+            {
+                uint32_t want = std::min<uint32_t>(64u, (4096u + active_tiles - 1u) / std::max(active_tiles, 1u));
+                if (const char* v = std::getenv("SPT_PRIMARY_CHUNKS")) want = (uint32_t)std::max(1, std::atoi(v));
+                want = std::max(1u, std::min(want, rc.pass_samples));
+                rc.chunk_samples = (rc.pass_samples + want - 1u) / want;
+                rc.primary_chunks = (rc.pass_samples + rc.chunk_samples - 1u) / rc.chunk_samples;
+            }
+            if (rc.primary_chunks > 1u) {
+                if (L) hipLaunchKernelGGL((k_primary<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                else hipLaunchKernelGGL((k_primary<false, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+            } else {
+                if (L) hipLaunchKernelGGL((k_primary<true, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                else hipLaunchKernelGGL((k_primary<false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+            }
             end();
             for (uint32_t b = 0; b < p.max_depth; ++b) {
                 begin(b == 0 ? SPT_K_SHADE_FIRST : SPT_K_SHADE);

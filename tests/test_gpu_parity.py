@@ -124,6 +124,22 @@ def test_shard_layout_does_not_change_pixels(spt):
     assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
 
 
+def test_sample_chunks_of_the_primary_kernel_do_not_change_pixels(spt, monkeypatch):
+    """k_primary<., kChunked>: any split of a pass's samples over workgroups gives the un-chunked film, also for a
+    narrow shard (1 of 8) and with an environment (every miss writes its term into its own slot)."""
+    for scene_name, cam in (("cfg2_cube.json", None), ("t_materials.json", "main")):
+        sc = _scene(spt, scene_name)
+        r = spt.PathTracer(max_depth=6, sampler=spt.SAMPLER_RANDOM, spp=24, seed=9)
+        cfg = spt.OutputConfig(112, 96, None, cam)
+        films = []
+        for chunks in ("1", "3", "24", "64"):
+            monkeypatch.setenv("SPT_PRIMARY_CHUNKS", chunks)
+            films.append(r.render_shard(sc, cfg, samples_per_pass=24))
+            films.append(r.render_shard(sc, cfg, shard_index=1, shard_count=8, strip_rows=4, samples_per_pass=10))
+        for k in range(2, len(films)):
+            assert np.array_equal(films[k].view(np.uint32), films[k % 2].view(np.uint32)), k
+
+
 def test_render_error_paths(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=4)
