@@ -197,7 +197,10 @@ def main():
         seg_s0, verts1 = st.shadow_first, st.vertices_second        # bounce 0: shadow rays issued, vertices kept for bounce 1
         later = verts - hits0                                        # path vertices of bounces >= 1
         alg = {
-            "primary": hits0 * (S_PATH0 + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
+            # un-chunked: hit records + a zeroed slot per hit + film read / write; chunked (sample chunks per tile): every
+            # sample of a pixel inside the screen-space bound zeroes / fills its slot, the film is left to k_resolve
+            "primary": (hits0 * (S_PATH0 + S_HIT) + st.live_samples * S_RAD) if st.live_samples else
+                       hits0 * (S_PATH0 + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
             # bounce-0 shade launches (one per pass): read the compact hit records, (fused) write the kept bounce-1
             # vertices and read-modify-write a radiance slot per shadow ray, (un-fused) write shadow + path records
             "shade_first": (hits0 * (S_PATH0 + S_HIT) + verts1 * (S_PATH + S_HIT) + seg_s0 * 2 * S_RAD) if fused else
@@ -206,7 +209,7 @@ def main():
                      later * (S_PATH + S_HIT) + (seg_s - seg_s0) * S_SHADOW + max(ext - hits0, 0) * S_PATH,
             "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
             "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
-            "resolve": hits0 * S_RAD + passes * n_pix * 2 * S_RAD,
+            "resolve": (st.live_samples if st.live_samples else hits0) * S_RAD + passes * n_pix * 2 * S_RAD,
         }
         kern = {}
         for k in (0, 6, 1, 2, 3, 4):

@@ -308,6 +308,8 @@ typedef struct spt_render_stats {
     uint64_t path_vertices;        /* records consumed by the shade stage over all bounces     */
     uint64_t shadow_first;         /* any-hit segments issued by the bounce-0 shade launches   */
     uint64_t vertices_second;      /* path vertices of bounce 1 (= extension rays of bounce 0 that were kept) */
+    uint64_t live_samples;         /* chunked k_primary: camera samples of pixels inside the screen-space bound, each of
+                                      which owns a radiance slot; 0 when the un-chunked kernel ran */
 } spt_render_stats;
 
 /* Closest-hit record: what BvhAccel/Group::intersect leave in `Intersection`

@@ -166,7 +166,7 @@ class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments_closest", C.c_uint64), ("segments_shadow", C.c_uint64),
                 ("gpu_ms", C.c_double), ("kernel_ms", C.c_double * N_KERNELS),
                 ("kernel_launches", C.c_uint32 * N_KERNELS), ("primary_hits", C.c_uint64),
-                ("path_vertices", C.c_uint64), ("shadow_first", C.c_uint64), ("vertices_second", C.c_uint64)]
+                ("path_vertices", C.c_uint64), ("shadow_first", C.c_uint64), ("vertices_second", C.c_uint64), ("live_samples", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("instance", "<i4"), ("prim", "<i4"), ("v", "<f4"), ("w", "<f4")])

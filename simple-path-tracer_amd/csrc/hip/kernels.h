@@ -796,7 +796,20 @@ __global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
     if (first >= rc.pass_samples) return;
     const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
     f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
-    for (uint32_t s = first; s < rc.pass_samples; ++s) {
+    // the additions are sequential (sample order = the reference's, film.rs:87), the loads are not: 8 samples
+    // (24 loads) in flight per lane, which matters when a narrow shard leaves few pixels to hide latency with
+    uint32_t s = first;
+    for (; s + 8u <= rc.pass_samples; s += 8u) {
+        float r[8], g[8], b[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const size_t ri = (size_t)(s + k) * rc.n_pixels + lp;
+            r[k] = rc.rad[ri]; g[k] = rc.rad[plane + ri]; b[k] = rc.rad[2 * plane + ri];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) sum = sum + mk3(r[k], g[k], b[k]);
+    }
+    for (; s < rc.pass_samples; ++s) {
         const size_t ri = (size_t)s * rc.n_pixels + lp;
         sum = sum + mk3(rc.rad[ri], rc.rad[plane + ri], rc.rad[2 * plane + ri]);  // film.rs:87
     }
