@@ -309,10 +309,12 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // 48-B shadow + 72-B path records (written once, read once: 240 B per path vertex) never touch HBM.
 // Next-bounce vertices go to (qb, hits_next); the host swaps the two buffer pairs every bounce.
 // (139 VGPRs for kFeat 0 = 3 waves / SIMD; forcing 128 with a launch bound spills 12 and measured the same.)
-template <int kFeat, bool kFirst, bool kFused = false>
+// kTab: the shading tables are read from the LDS-staged blob (tab_ld); always with kFused, and for the un-fused
+// general kernel of any scene whose geometry + tables fit LDS.
+template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     constexpr bool kSimple = kFeat == 0, kTex = kFeat == 2;
-    if (kFused) stage_geometry<true>(sc);
+    if (kFused || kTab) stage_geometry<true>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
     uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
     // fused bounce 0: the hit record of the NEXT iteration is requested before this iteration's shading and
     // traversals, so its HBM latency is hidden behind them (3 waves / SIMD cannot hide it otherwise)
-    constexpr bool kPrefetch = kFused && kFirst;
+    constexpr bool kPrefetch = (kFused || kTab) && kFirst;
     float4 pre_hv = make_float4(0, 0, 0, 0), pre_b = make_float4(0, 0, 0, 0);
     int32_t pre_inst = -1;
     const uint32_t i_first = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u);
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             DInter it;
             it.prim_type = 0u; it.prim_id = 0u;
             if (does_hit) {
-                it = reconstruct_hit<kTex, kFused>(sc, ray, h);
+                it = reconstruct_hit<kTex, kTab>(sc, ray, h);
                 if (kTex && kFirst) calc_differential(it, ray, h.t, rc.cam.eye, aux_xd, rc.cam.eye, aux_yd);   // pt.rs:51-53
             }
 
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     // still in the medium: in-scattering from one light sample
                     lsi = pi;
                     DLightSample ls;
-                    if (sample_light<false, kTex>(sc, lsi, rng, &ls)) {
+                    if (sample_light<false, kTex, kTab>(sc, lsi, rng, &ls)) {
                         float phase = henyey_greenstein(md.g, dot(wo, ls.dir));
                         // shadow_ray_from_medium (pt.rs:212-233): probe the last-hit basic primitive
                         // with the world-space ray, in its own object space
@@ -493,9 +495,9 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     }
                     alive = false;
                 } else {  // pt.rs:112-193
-                    const spt_surface sf = load_surface<kFused>(sc, it.surface);
+                    const spt_surface sf = load_surface<kTab>(sc, it.surface);
                     const uint32_t sflags = sf.flags;
-                    DMat mt = material_at<kTex, kFused>(sc, sf.material, it);
+                    DMat mt = material_at<kTex, kTab>(sc, sf.material, it);
                     if (kSimple) mt.bxdf = SPT_BXDF_LAMBERT;
                     DCoord coord = surface_coord<kTex>(sc, sf, ray, it);
                     f3 po = it.position;
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     lsi = po;
                     if (!mat_is_delta(mt)) {
                         DLightSample ls;
-                        if (sample_light<kSimple, kTex, kFused>(sc, lsi, rng, &ls)) {
+                        if (sample_light<kSimple, kTex, kTab>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
                             f3 f = mat_eval(mt, wo, wi);
                             float mpdf = mat_pdf(mt, wo, wi);

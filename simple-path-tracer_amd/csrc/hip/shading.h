@@ -991,7 +991,7 @@ SPT_DEV float instance_pdf(const DScene& sc, uint32_t inst, const DInter& it, in
 
 // kDeltaOnly: the scene has only directional / point / spot lights (checked on the host), so the
 // area-light and environment branches are not even compiled into the kernel.
-template <bool kDeltaOnly, bool kTex = false>
+template <bool kDeltaOnly, bool kTex = false, bool kL = false>
 SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRng& rng, DLightSample* out) {
     uint32_t type = l.type;
     if (kDeltaOnly && type > SPT_LIGHT_SPOT) type = SPT_LIGHT_DIRECTIONAL;
@@ -1017,8 +1017,8 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
     }
     case SPT_LIGHT_SHAPE: {  // shape_light.rs:20-42
         if (kDeltaOnly) return;
-        DInstance in = load_instance(sc, l.instance);
-        const spt_surface& sf = sc.surfaces[in.surface];
+        DInstance in = load_instance<kL>(sc, l.instance);
+        const spt_surface sf = load_surface<kL>(sc, in.surface);
         f3 spos, snrm;
         float spdf;
         DInter at;
@@ -1064,13 +1064,13 @@ SPT_DEV bool sample_light(const DScene& sc, f3 position, DRng& rng, DLightSample
     if (sc.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS) {
         float pr;
         uint32_t index = alias_sample(sc.light_props, sc.light_u, sc.light_k, sc.n_lights, rng.next(), &pr);
-        light_sample<kDeltaOnly, kTex>(sc, load_light<kL>(sc, index), position, rng, out);
+        light_sample<kDeltaOnly, kTex, kL>(sc, load_light<kL>(sc, index), position, rng, out);
         out->pdf = pr * out->pdf;
     } else {
         float fi = rng.next() * (float)sc.n_lights;
         uint32_t index = spt_f2u_sat(fi);
         if (index > sc.n_lights - 1) index = sc.n_lights - 1;
-        light_sample<kDeltaOnly, kTex>(sc, load_light<kL>(sc, index), position, rng, out);
+        light_sample<kDeltaOnly, kTex, kL>(sc, load_light<kL>(sc, index), position, rng, out);
         out->pdf = out->pdf * (1.0f / (float)sc.n_lights);
     }
     return true;

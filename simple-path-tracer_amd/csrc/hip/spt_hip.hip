@@ -441,7 +441,8 @@ struct spt_scene {
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
     bool bs_valid = false;
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
-    bool fused = false;     // k_shade<0, ., kFused> can run: geometry AND shading tables staged in LDS
+    bool lds_tables = false;  // the shading tables fit LDS behind the geometry (k_shade<.., kTab>)
+    bool fused = false;     // k_shade<0, ., kFused> can run: lds_tables and a simple scene
     bool textured = false;  // a material recipe, normal map or emissive map samples textures per hit (k_shade<2, .>)
     DeviceBuffer textures, tex_prog, tex_root, tex_chain, images, image_levels, texels, recipes;
     std::vector<hipEvent_t> events;
@@ -760,8 +761,9 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 }
                 const size_t extra = (size_t)s.n_tris * sizeof(spt_tri_attr) + (size_t)s.n_surfaces * sizeof(spt_surface) +
                                      (size_t)s.n_materials * sizeof(spt_material) + (size_t)s.n_lights * sizeof(spt_light) + 64;
-                sc->fused = sc->lds_geo && simple_scene && blob.size() * 16 + extra <= 32u * 1024u && stack_bytes + blob.size() * 16 + extra <= 64u * 1024u;
-                if (sc->fused) {
+                sc->lds_tables = sc->lds_geo && blob.size() * 16 + extra <= 32u * 1024u && stack_bytes + blob.size() * 16 + extra <= 64u * 1024u;
+                sc->fused = sc->lds_tables && simple_scene;
+                if (sc->lds_tables) {
                     d.o_attr = append(s.tri_attr, (size_t)s.n_tris * sizeof(spt_tri_attr));
                     d.o_surf = append(s.surfaces, (size_t)s.n_surfaces * sizeof(spt_surface));
                     d.o_mat = append(s.materials, (size_t)s.n_materials * sizeof(spt_material));
@@ -1147,16 +1149,17 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     end();
                     continue;
                 }
-                if (sc->simple) {
-                    if (b == 0) hipLaunchKernelGGL((k_shade<0, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                    else hipLaunchKernelGGL((k_shade<0, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                } else if (!sc->textured) {
-                    if (b == 0) hipLaunchKernelGGL((k_shade<1, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                    else hipLaunchKernelGGL((k_shade<1, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                } else {
-                    if (b == 0) hipLaunchKernelGGL((k_shade<2, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                    else hipLaunchKernelGGL((k_shade<2, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);
-                }
+                const bool tab = sc->lds_tables && std::getenv("SPT_NO_LDS_TABLES") == nullptr;   // shading tables from LDS (tab_ld)
+#define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
+    if (tab) {                                                                                                                                 \
+        if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
+        else hipLaunchKernelGGL((k_shade<FEAT, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);              \
+    } else {                                                                                                                                   \
+        if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);                       \
+        else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);                             \
+    }
+                if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else { SPT_LAUNCH_SHADE(2) }
+#undef SPT_LAUNCH_SHADE
                 end();
                 begin(SPT_K_SHADOW);
                 if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
