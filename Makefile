@@ -35,7 +35,7 @@ $(LIBDIR)/libspt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
-$(LIBDIR)/spt: $(PKG)/csrc/cli/main.cpp $(LIBDIR)/libspt_host.so $(LIBDIR)/libspt_hip.so
+$(LIBDIR)/spt: $(PKG)/csrc/cli/main.cpp $(wildcard include/*.h) $(LIBDIR)/libspt_host.so $(LIBDIR)/libspt_hip.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lspt_host -lspt_hip -Wl,-rpath,'$$ORIGIN'
 
 clean:

@@ -676,7 +676,8 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
 // MEASURED (1 M-triangle scene, 1024^2 x 32 spp): shadow 8.8 ms vs 10.9 ms nested (any-hit walks end at
 // very different times, so refilling pays), extend 28 ms vs 20 ms nested (every lane walks to the end
 // anyway and the one-step-per-call state machine costs more than the idle lanes it saves).  Hence the
-// default: k_shadow_dyn on, k_extend_dyn off (SPT_DYN_EXTEND=1 / SPT_NO_DYN_SHADOW=1 to flip).
+// (that was with the 2-wide nodes; with the 4-wide nodes k_extend_dyn wins too, 16.0 vs 17.7 ms).  Default: both on
+// for scenes that do not fit LDS (SPT_NO_DYN_SHADOW=1 / SPT_NO_DYN_EXTEND=1 switch them off).
 // First version kept the spill array inside the walker struct, which dragged the whole walker into
 // scratch memory (40 scratch loads/stores per step) and made it 2.4x slower than nested.
 constexpr uint32_t kRefillBelow = 40;   // refill when fewer lanes than this are walking
