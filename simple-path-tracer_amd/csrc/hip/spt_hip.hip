@@ -44,9 +44,13 @@ int usable_device_count() {
     return n;
 }
 
-struct DeviceBuffer {
+struct DeviceBuffer {   // owning: freed with the scene object (the owner selects the device first)
     void* p = nullptr;
     size_t bytes = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
     void alloc(size_t n) {
         release();
         if (n == 0) n = 16;
@@ -429,7 +433,7 @@ struct spt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     DScene d{};
-    DeviceBuffer tlas, blas, tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
+    DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
     DeviceBuffer light_props, light_u, light_k, env_texels, env_props, env_u, env_k, geo;
     bool lds_geo = false;   // traversal geometry small enough to live in LDS (k_*<true>)
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
@@ -622,8 +626,6 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         uint32_t cap = tlas_depth + blas_depth + 2;
         if (!own_bvh && cap > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (48 levels)");
         if (tlas_depth + 2 > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "TLAS deeper than the traversal stack (48 levels)");
-        sc->tlas.upload(s.tlas_nodes, s.n_tlas_nodes);
-        sc->blas.upload(s.blas_nodes, s.n_blas_nodes);
         sc->tri_pos.upload(s.tri_pos, s.n_tris);
         sc->tri_attr.upload(s.tri_attr, s.n_tris);
         sc->instances.upload(s.instances, s.n_instances);
@@ -643,8 +645,6 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         sc->env_u.upload(s.env.alias.u, ne);
         sc->env_k.upload(s.env.alias.k, ne);
         DScene& d = sc->d;
-        d.tlas_nodes = sc->tlas.as<float4>();
-        d.blas_nodes = sc->blas.as<float4>();
         d.tri_pos = sc->tri_pos.as<float4>();
         d.tri_attr = sc->tri_attr.as<float4>();
         d.instances = sc->instances.as<float4>();
@@ -900,15 +900,7 @@ void spt_scene_destroy(spt_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     (void)hipStreamSynchronize(scene->stream);
-    DeviceBuffer* all[] = {&scene->tlas, &scene->blas, &scene->tri_pos, &scene->tri_attr, &scene->instances, &scene->meshes,
-                           &scene->spheres, &scene->surfaces, &scene->materials, &scene->mediums, &scene->lights,
-                           &scene->light_props, &scene->light_u, &scene->light_k, &scene->env_texels, &scene->env_props,
-                           &scene->env_u, &scene->env_k, &scene->hit_f4, &scene->hit_inst, &scene->counts, &scene->rad,
-                           &scene->film, &scene->first_slot, &scene->out, &scene->trace_in, &scene->trace_out, &scene->geo};
-    for (auto* b : all) b->release();
-    for (auto& b : scene->qa) b.release();
-    for (auto& b : scene->qb) b.release();
-    for (auto& b : scene->sh) b.release();
+    // every DeviceBuffer member frees itself (a list here used to miss the buffers added later)
     delete scene;
 }
 

@@ -19,8 +19,6 @@
 #include "device_math.h"
 
 struct DScene {
-    const float4* tlas_nodes;  // 2 x float4 per node: (bmin, a) (bmax, b)
-    const float4* blas_nodes;
     const float4* tri_pos;     // 3 x float4 per triangle
     const float4* tri_attr;    // 9 x float4 per triangle (spt_tri_attr)
     const float4* instances;   // 12 x float4 per instance (spt_instance)
