@@ -19,6 +19,16 @@ ORACLE_SLAB_RECIPROCAL, ORACLE_BRUTE_FORCE, ORACLE_LIBM, ORACLE_TIE_MIN_ID = 1, 
 # the oracle configuration the kernels are compared against: reciprocal slab test and the
 # order-independent (t, instance, prim) tie rule (the kernels walk near children first)
 ORACLE_DEVICE = ORACLE_SLAB_RECIPROCAL | ORACLE_TIE_MIN_ID
+# What the HIP path must reproduce bit-for-bit.  By default libspt_hip walks its OWN (padded, conservative) trees, so
+# it finds every triangle the reference's triangle test accepts: the tree-INDEPENDENT answer = the oracle without any
+# box culling (ORACLE_BRUTE_FORCE) under the order-independent tie rule.  With SPT_REFERENCE_BVH=1 it walks the
+# caller's trees with the oracle's reciprocal slab arithmetic: the tree-dependent answer (ORACLE_DEVICE), which can
+# lose a hit whose ray grazes the edge of an exact bounding box (about one ray in 1e7 on the test scenes).
+ORACLE_EXHAUSTIVE = ORACLE_BRUTE_FORCE | ORACLE_TIE_MIN_ID
+
+
+def device_oracle_flags():
+    return ORACLE_DEVICE if os.environ.get("SPT_REFERENCE_BVH") else ORACLE_EXHAUSTIVE
 
 
 def load_pkg():
