@@ -36,10 +36,11 @@ def test_trace_closest_and_any_bit_exact(spt, scene_name):
     got = sc.device_scene(0).trace_closest(rays)
     assert ref["instance"].max() >= 0, "test rays never hit"
     same_t = ref["t"].view(np.uint32) == got["t"].view(np.uint32)
-    # The random rays also come from below the floor, where objects resting on it give COINCIDENT
-    # surfaces: there box culling against an equal-depth candidate depends on the visit order (the
-    # slab distance of a flat box and the triangle distance differ in the last bit).  Everywhere else
-    # the closest hit must be bit-identical.
+    # Default mode (own trees vs the exhaustive oracle): every ray bit-identical, asserted below.
+    # SPT_REFERENCE_BVH=1 (caller's trees vs the tree-walking oracle): the random rays also come from below the
+    # floor, where objects resting on it give COINCIDENT surfaces; there box culling against an equal-depth
+    # candidate depends on the visit order (the slab distance of a flat box and the triangle distance differ in
+    # the last bit), hence the tolerance for the t_ scenes in that mode only.
     assert same_t.mean() > 0.997, same_t.mean()
     assert np.array_equal(ref["instance"] >= 0, got["instance"] >= 0)
     hit = ref["instance"] >= 0
@@ -48,8 +49,8 @@ def test_trace_closest_and_any_bit_exact(spt, scene_name):
         assert np.array_equal(ref[f][same_t], got[f][same_t]), f
     for f in ("v", "w"):
         assert np.array_equal(ref[f][same_t].view(np.uint32), got[f][same_t].view(np.uint32)), f
-    if not scene_name.startswith("t_"):
-        assert same_t.all()
+    if not scene_name.startswith("t_") or not os.environ.get("SPT_REFERENCE_BVH"):
+        assert same_t.all()      # own trees vs the exhaustive oracle: no box in either, nothing depends on visit order
     # any-hit with finite t_max taken around the closest hits
     rays2 = rays.copy()
     rays2["t_max"] = np.where(ref["instance"] >= 0, ref["t"] * np.float32(1.5), np.float32(5.0)).astype(np.float32)
@@ -58,7 +59,7 @@ def test_trace_closest_and_any_bit_exact(spt, scene_name):
     occ = sc.device_scene(0).trace_any(rays2)
     assert 0 < occ_ref.sum() < len(occ_ref)
     assert (occ_ref != occ).mean() < 1e-3
-    if not scene_name.startswith("t_"):
+    if not scene_name.startswith("t_") or not os.environ.get("SPT_REFERENCE_BVH"):
         assert np.array_equal(occ_ref, occ)
 
 
