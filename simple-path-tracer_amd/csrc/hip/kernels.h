@@ -321,24 +321,30 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
     uint32_t* ext_count = q_count(rc.counts, bounce, Q_EXT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
-    // fused bounce 0: the hit record of the NEXT iteration is requested before this iteration's shading and
-    // traversals, so its HBM latency is hidden behind them (3 waves / SIMD cannot hide it otherwise)
-    constexpr bool kPrefetch = (kFused || kTab) && kFirst;
+    // the queue record of the NEXT iteration is requested before this iteration's shading (and traversals), so
+    // its HBM latency is hidden behind them (2 - 3 waves / SIMD cannot hide it otherwise)
+    constexpr bool kPrefetch = true;                 // (hit, direction / slot, instance): 9 registers
+    constexpr bool kPrefetchPath = !kFirst && kSimple;   // + the rest of the 72-byte path record: 14 more (k_shade<1> would reach 260 VGPRs = 1 wave / SIMD)
     float4 pre_hv = make_float4(0, 0, 0, 0), pre_b = make_float4(0, 0, 0, 0);
+    float4 pre_a = pre_hv, pre_c = pre_hv, pre_d = pre_hv;
+    uint2 pre_rs = make_uint2(0u, 0u);
     int32_t pre_inst = -1;
     const uint32_t i_first = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u);
     if (kPrefetch && i_first + lane_id() < n) {
         const uint32_t k = qbase + i_first + lane_id();
         pre_hv = rc.hits.t_v_w_prim[k]; pre_b = rc.qa.d_pdf[k]; pre_inst = rc.hits.inst[k];
+        if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
     }
     for (uint32_t i0 = i_first; i0 < n; i0 += stride) {
         const bool active = i0 + lane_id() < n;
         const uint32_t idx = qbase + i0 + lane_id();
-        const float4 cur_hv = pre_hv, cur_b = pre_b;
+        const float4 cur_hv = pre_hv, cur_b = pre_b, cur_a = pre_a, cur_c = pre_c, cur_d = pre_d;
+        const uint2 cur_rs = pre_rs;
         const int32_t cur_inst = pre_inst;
         if (kPrefetch && i0 + stride + lane_id() < n) {
             const uint32_t k = idx + stride;
             pre_hv = rc.hits.t_v_w_prim[k]; pre_b = rc.qa.d_pdf[k]; pre_inst = rc.hits.inst[k];
+            if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
         }
         bool want_shadow = false, want_ext = false;
         DRay shadow_ray, next_ray;
@@ -383,8 +389,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 depth = 0u;
                 medium = -1;
             } else {
-                float4 a = rc.qa.o_tmin[idx], b = rc.qa.d_pdf[idx], c = rc.qa.thr_slot[idx], d = rc.qa.lsi_meta[idx];
-                uint2 rs = rc.qa.rng[idx];
+                const float4 b = cur_b;
+                float4 a, c, d;
+                uint2 rs;
+                if (kPrefetchPath) { a = cur_a; c = cur_c; d = cur_d; rs = cur_rs; }
+                else { a = rc.qa.o_tmin[idx]; c = rc.qa.thr_slot[idx]; d = rc.qa.lsi_meta[idx]; rs = rc.qa.rng[idx]; }
                 ray.o = mk3(a); ray.t_min = a.w;
                 ray.d = mk3(b);
                 last_pdf = b.w;
