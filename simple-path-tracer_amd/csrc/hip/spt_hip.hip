@@ -432,6 +432,8 @@ uint32_t build_n4(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>&
 struct spt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: k_shadow(b) next to k_extend(b) (see spt_render)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DScene d{};
     DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
     DeviceBuffer light_props, light_u, light_k, env_texels, env_props, env_u, env_k, geo;
@@ -453,6 +455,9 @@ struct spt_scene {
     ~spt_scene() {
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -613,6 +618,9 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         sc = new spt_scene();
         sc->device = device;
         HIP_CHECK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
         const spt_scene_desc& s = *desc;
         // stack need: reference-order traversal holds at most depth+1 entries per level of nesting
         uint32_t tlas_depth = 0, blas_depth = 0;
@@ -1047,6 +1055,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
 
         hipStream_t st = sc->stream;
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
+        // per-kernel event timing needs one stream; so does a scene with an environment (see the bounce loop)
+        const bool overlap = !profile && sc->d.env_w == 0u && std::getenv("SPT_NO_OVERLAP") == nullptr;
         const size_t lds = sc->lds_bytes;
         const bool L = sc->lds_geo;
         // refilling persistent waves for large scenes: on for shadow rays (any-hit walks end at very
@@ -1159,11 +1169,22 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else { SPT_LAUNCH_SHADE(2) }
 #undef SPT_LAUNCH_SHADE
                 end();
+                // k_shadow(b) and k_extend(b) are independent unless the scene has an environment (then a missing
+                // extension ray adds its term to the same radiance slot the shadow ray of that vertex adds to, and
+                // the reference's order of the two additions has to be kept): without one, the shadow kernel runs on
+                // a side stream next to the extension kernel and is joined before the next stage reads the slots.
+                const bool side = overlap && b + 1 < p.max_depth;
+                hipStream_t ss = side ? sc->stream2 : st;
+                if (side) {
+                    HIP_CHECK(hipEventRecord(sc->ev_fork, st));
+                    HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
+                }
                 begin(SPT_K_SHADOW);
-                if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
                 end();
+                if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
                 if (b + 1 < p.max_depth) {
                     begin(SPT_K_EXTEND);
                     if (L) hipLaunchKernelGGL(k_extend<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
@@ -1171,6 +1192,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     else hipLaunchKernelGGL(k_extend<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                     end();
                 }
+                if (side) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_join, 0));
             }
             begin(SPT_K_RESOLVE);
             hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
