@@ -884,13 +884,13 @@ SPT_DEV void env_lookup(const DScene& sc, float theta, float phi, f3* c_out, flo
     uint32_t uy1 = (uint32_t)(y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1));
     size_t i00 = (size_t)uy0 * sc.env_w + ux0, i01 = (size_t)uy1 * sc.env_w + ux0;
     size_t i10 = (size_t)uy0 * sc.env_w + ux1, i11 = (size_t)uy1 * sc.env_w + ux1;
-    f3 c00 = mk3(sc.env_texels + 3 * i00), c01 = mk3(sc.env_texels + 3 * i01);
-    f3 c10 = mk3(sc.env_texels + 3 * i10), c11 = mk3(sc.env_texels + 3 * i11);
+    const float4 t00 = sc.env_px[i00], t01 = sc.env_px[i01], t10 = sc.env_px[i10], t11 = sc.env_px[i11];
+    f3 c00 = mk3(t00), c01 = mk3(t01), c10 = mk3(t10), c11 = mk3(t11);
     f3 c0 = c00 * (1.0f - yt) + c01 * yt;
     f3 c1 = c10 * (1.0f - yt) + c11 * yt;
     f3 c = c0 * (1.0f - xt) + c1 * xt;
-    float p0 = sc.env_props[i00] * (1.0f - yt) + sc.env_props[i01] * yt;
-    float p1 = sc.env_props[i10] * (1.0f - yt) + sc.env_props[i11] * yt;
+    float p0 = t00.w * (1.0f - yt) + t01.w * yt;
+    float p1 = t10.w * (1.0f - yt) + t11.w * yt;
     *p_out = p0 * (1.0f - xt) * p1 * xt;
     *c_out = c * mk3(sc.env_scale);
 }
@@ -1040,8 +1040,14 @@ SPT_DEV void light_sample(const DScene& sc, const spt_light& l, f3 position, DRn
     }
     default: {  // environment.rs:110-126
         if (kDeltaOnly) return;
-        float pr;
-        uint32_t ind = alias_sample(sc.env_props, sc.env_u, sc.env_k, sc.env_w * sc.env_h, rng.next(), &pr);
+        uint32_t ind;   // alias_sample (alias_table.rs:60-68) on the packed table; the returned probability is
+        {               // not used by EnvLight::sample (the pdf comes from the bilinear lookup below, quirk Q5)
+            const float temp = rng.next() * (float)(sc.env_w * sc.env_h);
+            const uint32_t x = spt_f2u_sat(temp);
+            const float y = temp - (float)x;
+            const uint2 uk = sc.env_uk[x];
+            ind = (y < __uint_as_float(uk.x)) ? x : uk.y;
+        }
         uint32_t x = ind % sc.env_w, y = ind / sc.env_w;
         float rx = rng.next(), ry = rng.next();
         float theta = ((float)y + ry) / (float)sc.env_h * SPT_PI;

@@ -436,7 +436,7 @@ struct spt_scene {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DScene d{};
     DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
-    DeviceBuffer light_props, light_u, light_k, env_texels, env_props, env_u, env_k, geo;
+    DeviceBuffer light_props, light_u, light_k, env_px, env_uk, geo;
     bool lds_geo = false;   // traversal geometry small enough to live in LDS (k_*<true>)
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
@@ -648,10 +648,18 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         sc->light_u.upload(s.light_alias.u, pis ? s.n_lights : 0);
         sc->light_k.upload(s.light_alias.k, pis ? s.n_lights : 0);
         size_t ne = (size_t)s.env.width * s.env.height;
-        sc->env_texels.upload(s.env.texels, ne * 3);
-        sc->env_props.upload(s.env.alias.props, ne);
-        sc->env_u.upload(s.env.alias.u, ne);
-        sc->env_k.upload(s.env.alias.k, ne);
+        {
+            std::vector<float4> px(ne);
+            std::vector<uint2> uk(ne);
+            for (size_t i = 0; i < ne; ++i) {
+                px[i] = make_float4(s.env.texels[3 * i], s.env.texels[3 * i + 1], s.env.texels[3 * i + 2], s.env.alias.props[i]);
+                uint32_t ub;
+                std::memcpy(&ub, &s.env.alias.u[i], 4);
+                uk[i] = make_uint2(ub, s.env.alias.k[i]);
+            }
+            sc->env_px.upload(px.data(), ne);
+            sc->env_uk.upload(uk.data(), ne);
+        }
         DScene& d = sc->d;
         d.tri_pos = sc->tri_pos.as<float4>();
         d.tri_attr = sc->tri_attr.as<float4>();
@@ -665,10 +673,8 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         d.light_props = sc->light_props.as<float>();
         d.light_u = sc->light_u.as<float>();
         d.light_k = sc->light_k.as<uint32_t>();
-        d.env_texels = sc->env_texels.as<float>();
-        d.env_props = sc->env_props.as<float>();
-        d.env_u = sc->env_u.as<float>();
-        d.env_k = sc->env_k.as<uint32_t>();
+        d.env_px = sc->env_px.as<float4>();
+        d.env_uk = sc->env_uk.as<uint2>();
         d.n_tlas_nodes = s.n_tlas_nodes;
         d.n_instances = s.n_instances;
         d.n_lights = s.n_lights;

@@ -29,7 +29,9 @@ struct DScene {
     const spt_medium* mediums;
     const spt_light* lights;
     const float* light_props; const float* light_u; const uint32_t* light_k;
-    const float* env_texels; const float* env_props; const float* env_u; const uint32_t* env_k;
+    // environment map, packed for the two access patterns (one line instead of four per bilinear tap / alias draw):
+    const float4* env_px;      // per texel: (r, g, b, alias-table probability `props`)
+    const uint2* env_uk;       // per texel: alias table (u bits, k)
     uint32_t n_tlas_nodes, n_instances, n_lights, n_meshes;
     uint32_t aggregate, light_sampler;
     int32_t env_light_index;
