@@ -260,7 +260,11 @@ class Scene:
     def desc(self) -> SceneDesc:
         return host_lib().spt_host_scene_desc(self._h).contents
 
-    def get_camera(self, name: Optional[str] = None) -> Camera:
+    def get_camera(self, name=None) -> Camera:
+        """Scene::get_camera (src/core/scene.rs): by name, the first one for None; a Camera instance is passed through
+        (callers that place their own camera, e.g. tests)."""
+        if isinstance(name, Camera):
+            return name
         cam = Camera()
         _check_host(host_lib().spt_host_scene_camera(self._h, name.encode() if name else None, C.byref(cam)))
         return cam
@@ -430,6 +434,21 @@ class PathTracer:
         if config.output_filename:
             write_png(config.output_filename, film)
         return film
+
+
+def make_camera(eye, forward, up, fov_degrees: float) -> Camera:
+    """PerspectiveCamera::new (src/camera/perspective.rs:15-27) from f32 vectors."""
+    f32 = np.float32
+    e, f, u = (np.asarray(v, dtype=f32) for v in (eye, forward, up))
+    f = f / f32(np.sqrt(f32(np.dot(f, f))))
+    r = np.cross(f, u).astype(f32)
+    r = r / f32(np.sqrt(f32(np.dot(r, r))))
+    u = np.cross(r, f).astype(f32)
+    cam = Camera()
+    for k in range(3):
+        cam.eye[k], cam.forward[k], cam.up[k], cam.right[k] = float(e[k]), float(f[k]), float(u[k]), float(r[k])
+    cam.half_cot_half_fov = float(f32(0.5) / f32(np.tan(f32(np.radians(fov_degrees)) * f32(0.5))))
+    return cam
 
 
 def load_renderer(path: str, seed: int = 1) -> PathTracer:

@@ -165,6 +165,38 @@ def test_larger_multi_pass_renders_match_oracle(spt, scene_name, camera, bvh, mo
     assert int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum()) == 0
 
 
+def test_screen_space_bound_with_arbitrary_cameras(spt):
+    """k_primary's pixel culling: cameras outside, at the edge of and INSIDE the scene's bounds, looking at, past and
+    away from it, narrow and very wide, on a non-square image rendered as shards - always the oracle's film."""
+    rng = np.random.default_rng(42)
+    for scene_name in ("cfg2_cube.json", "t_materials.json"):
+        sc = _scene(spt, scene_name)
+        inst = sc.array("instances")
+        lo, hi = inst["bmin"].min(axis=0), inst["bmax"].max(axis=0)
+        centre, ext = (lo + hi) * 0.5, float((hi - lo).max())
+        cams = []
+        for k in range(10):
+            radius = ext * (0.15, 0.6, 1.0, 2.5, 6.0)[k % 5]          # inside the bounds ... far away
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            eye = centre + d * radius
+            aim = centre + rng.normal(size=3) * ext * (0.0, 0.3, 1.5)[k % 3]   # at the scene ... past it
+            fwd = aim - eye if k != 7 else eye - centre                 # k = 7 looks away
+            up = (0.0, 1.0, 0.0) if abs(fwd[1]) < 0.95 * np.linalg.norm(fwd) else (1.0, 0.0, 0.0)
+            cams.append(spt.make_camera(eye, fwd, up, (20.0, 45.0, 90.0, 150.0)[k % 4]))
+        r = spt.PathTracer(max_depth=5, sampler=spt.SAMPLER_RANDOM, spp=4, seed=13)
+        w, h = 88, 56
+        for k, cam in enumerate(cams):
+            ref, _ = _util.oracle_render(sc, r, w, h, camera=cam, flags=_util.device_oracle_flags())
+            got = np.zeros_like(ref)
+            for s in range(3):
+                rows = spt.shard_rows(h, s, 3, 8)
+                got[rows] = r.render_shard(sc, spt.OutputConfig(w, h, None, cam), shard_index=s, shard_count=3, strip_rows=8)
+            nan = np.isnan(ref)
+            assert np.array_equal(nan, np.isnan(got)), (scene_name, k)
+            assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan]), (scene_name, k)
+
+
 def test_render_error_paths(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=4)
