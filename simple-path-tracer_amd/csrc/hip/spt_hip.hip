@@ -138,14 +138,18 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
         t[i].id = tri_first + i;
     }
     constexpr int kBins = 32;
-    constexpr uint32_t kMaxLeaf = 4;
-    constexpr float kTraversalCost = 1.2f;   // one wide-node visit (two slab tests) relative to one triangle test
+    // tuning knobs (defaults measured on cfg2 / cfg5; the environment overrides exist for that measurement only)
+    uint32_t kMaxLeaf = 4;
+    float kTraversalCost = 1.2f;   // one wide-node visit (two slab tests) relative to one triangle test
+    if (const char* v = std::getenv("SPT_BVH_MAX_LEAF")) kMaxLeaf = (uint32_t)std::min(15, std::max(1, std::atoi(v)));
+    if (const char* v = std::getenv("SPT_BVH_TRAVERSAL_COST")) kTraversalCost = (float)std::atof(v);
     auto half_area = [](const float* lo, const float* hi) {
         float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
     struct Task { uint32_t begin, end, node, depth; };
     std::vector<Task> st;
+    const size_t root_index = nodes.size();
     nodes.push_back(spt_bvh_node{});
     st.push_back(Task{0u, tri_count, (uint32_t)nodes.size() - 1u, 0u});
     while (!st.empty()) {
@@ -240,6 +244,15 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
         st.push_back(Task{tk.begin, mid, nd.a, tk.depth + 1u});
     }
     for (uint32_t i = 0; i < tri_count; ++i) order[tri_first + i] = t[i].id;
+    if (std::getenv("SPT_DEBUG_BVH")) {
+        uint32_t hist[16] = {}, leaves = 0, inner = 0;
+        for (size_t k = root_index; k < nodes.size(); ++k) {
+            if (nodes[k].b & SPT_LEAF_FLAG) { ++leaves; ++hist[std::min(15u, nodes[k].b & ~SPT_LEAF_FLAG)]; }
+            else ++inner;
+        }
+        std::fprintf(stderr, "[spt] device BLAS: %u triangles, %u inner nodes, %u leaves, leaf sizes 1:%u 2:%u 3:%u 4:%u >4:%u\n", tri_count, inner, leaves,
+                     hist[1], hist[2], hist[3], hist[4], leaves - hist[1] - hist[2] - hist[3] - hist[4]);
+    }
 }
 
 // Repack one 32-byte-node tree into 64-byte wide nodes (see trace.h).  Returns the index of the
