@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 4
+#define SPT_ABI_VERSION 5
 
 typedef int32_t spt_status;
 enum {
@@ -125,11 +125,12 @@ enum {
 /* plastic lobes = Fresnel-weighted specular coat over a substrate (materials plastic, pbr_metallic,
  * pbr_specular; src/material/{plastic,pbr_metallic,pbr_specular}.rs) */
 enum { SPT_FRESNEL_DIELECTRIC = 0, SPT_FRESNEL_SCHLICK = 1 };   /* src/bxdf/fresnel.rs:19-59 */
-enum { SPT_SUBSTRATE_LAMBERT = 0, SPT_SUBSTRATE_DIFFUSE = 1 };  /* src/bxdf/substrate.rs:22-45,120-180 */
+enum { SPT_SUBSTRATE_LAMBERT = 0, SPT_SUBSTRATE_DIFFUSE = 1,    /* src/bxdf/substrate.rs:22-45,120-180 */
+       SPT_SUBSTRATE_SUBSURFACE = 2 };                           /* substrate.rs:182-350: Diffuse + a BSSRDF probe ray */
 typedef struct spt_material {
     uint32_t bxdf;
     float c0[3];     /* lambert: reflectance; conductor: ior (eta); plastic: substrate reflectance */
-    float c1[3];     /* conductor: ior_k; plastic with Schlick Fresnel: r0                         */
+    float c1[3];     /* conductor: ior_k; plastic with Schlick Fresnel: r0; Subsurface substrate: d  */
     float ax, ay;    /* GGX roughness_x / roughness_y (as the material hands them to GgxMicrofacet) */
     float ior;       /* dielectric / plastic: int_ior / ext_ior                                     */
     float c2[3];     /* Diffuse substrate: bxdf_wo_fresnel (Diffuse::new, substrate.rs:127-137)     */
@@ -174,10 +175,10 @@ typedef struct spt_image_level { uint32_t width, height, first_texel, pad; } spt
 /* A material whose parameters are not all constant: MaterialT::bxdf_context
  * (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs) restated as data. */
 enum { SPT_MAT_LAMBERT = 0, SPT_MAT_CONDUCTOR = 1, SPT_MAT_DIELECTRIC = 2, SPT_MAT_PLASTIC = 3,
-       SPT_MAT_PBR_METALLIC = 4, SPT_MAT_PBR_SPECULAR = 5 };
+       SPT_MAT_PBR_METALLIC = 4, SPT_MAT_PBR_SPECULAR = 5, SPT_MAT_SUBSURFACE = 6 };
 typedef struct spt_material_recipe {
     uint32_t type;         /* SPT_MAT_* */
-    uint32_t tex[4];       /* texture indices: [0] albedo | ior | base_color | diffuse, [1] ior_k | metallic | specular,
+    uint32_t tex[4];       /* texture indices: [0] albedo | ior | base_color | diffuse, [1] ior_k | metallic | specular | ld,
                               [2] roughness_x, [3] roughness_y (unused slots: 0) */
     uint32_t rough_chan;   /* SPT_CHAN_* read from tex[2], tex[3] (the JSON loader always says R) */
     uint32_t metal_chan;   /* SPT_CHAN_* read from tex[1] of PBR_METALLIC                      */

@@ -199,6 +199,17 @@ SPT_HD float spt_trunc(float x) {
 /* f32::fract = x - trunc(x) */
 SPT_HD float spt_fract(float x) { return x - spt_trunc(x); }
 
+/* ---- BSSRDF radius table (src/bxdf/substrate.rs:187-196, SS_CDF_TABLE) -------------
+ * entry i of 512: x = -2 ln(1 - i/512), y = 1 - e^-x / 4 - 3 e^(-x/3) / 4 (the CDF of the normalised diffusion
+ * profile); host and device build the table from this one definition. */
+#define SPT_SS_CDF_SIZE 512
+SPT_HD void spt_ss_cdf_entry(uint32_t i, float* x_out, float* y_out) {
+    float x = (float)i / 512.0f;
+    x = -2.0f * spt_log(1.0f - x);
+    *x_out = x;
+    *y_out = 1.0f - spt_exp(-x) * 0.25f - spt_exp(-x / 3.0f) * 0.75f;
+}
+
 /* ---- atan / atan2 / asin / acos --------------------------------------------- */
 SPT_HD float spt_atan_pos(float x) { /* x >= 0 */
     float y;

@@ -698,6 +698,23 @@ inline spt_material material_at(const Ctx& cx, const spt_material& constant, con
         m.substrate = SPT_SUBSTRATE_LAMBERT;
         break;
     }
+    case SPT_MAT_SUBSURFACE: {  // material/subsurface.rs:66-93, bxdf::Subsurface::new (substrate.rs:199-211)
+        Color albedo = tex_color(cx, r.tex[0], in);
+        float ld = tex_float(cx, r.tex[1], in, SPT_CHAN_R);
+        m.ior = r.ior;
+        m.bxdf = roughness(true) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        m.fresnel = SPT_FRESNEL_DIELECTRIC;
+        m.substrate = SPT_SUBSTRATE_SUBSURFACE;
+        store(m.c0, albedo);
+        float fdr = 2.0f * fresnel_moment1(1.0f / r.ior);
+        store(m.c2, (albedo * SPT_FRAC_1_PI) / (((gray(1.0f) - albedo * fdr) * r.ior) * r.ior));
+        const float a[3] = {albedo.r, albedo.g, albedo.b};
+        for (int k = 0; k < 3; ++k) {
+            float q = a[k] - 0.33f, q2 = q * q;
+            m.c1[k] = ld / (3.5f + 100.0f * (q2 * q2));
+        }
+        break;
+    }
     default: {  // pbr_specular.rs:60-92
         store(m.c0, tex_color(cx, r.tex[0], in));
         store(m.c1, tex_color(cx, r.tex[1], in));
@@ -876,7 +893,7 @@ inline float substrate_pdf(const spt_material&, Vec3 wo, Vec3 wi) {
 }
 inline Color substrate_eval(const spt_material& mt, Vec3 wo, Vec3 wi) {
     if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
-    if (mt.substrate == SPT_SUBSTRATE_DIFFUSE) {
+    if (mt.substrate != SPT_SUBSTRATE_LAMBERT) {   // Diffuse, and Subsurface through its `diffuse` member (substrate.rs:339-349)
         float fi = fresnel_n(mt.ior, wi, v3(0, 0, 1));
         return (1.0f - fi) * col(mt.c2);
     }
@@ -892,7 +909,90 @@ bool bxdf_is_delta(const spt_material& mt) {
     return mt.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR || mt.bxdf == SPT_BXDF_SPECULAR_DIELECTRIC || mt.bxdf == SPT_BXDF_PSEUDO;
 }
 
-BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng) {
+// ---- Subsurface substrate (src/bxdf/substrate.rs:182-350) -----------------------------------------------
+struct SsCdfTable {
+    float x[SPT_SS_CDF_SIZE], y[SPT_SS_CDF_SIZE];
+    SsCdfTable() { for (uint32_t i = 0; i < SPT_SS_CDF_SIZE; ++i) spt_ss_cdf_entry(i, &x[i], &y[i]); }
+};
+inline const SsCdfTable& ss_cdf_table() { static const SsCdfTable t; return t; }
+inline float ss_sample_r(float rand) {  // substrate.rs:219-229
+    const SsCdfTable& t = ss_cdf_table();
+    for (uint32_t i = 1; i < SPT_SS_CDF_SIZE; ++i)
+        if (t.y[i] >= rand) {
+            float w = (rand - t.y[i - 1]) / (t.y[i] - t.y[i - 1]);
+            return t.x[i] * w + t.x[i - 1] * (1.0f - w);
+        }
+    return -1.0f;
+}
+inline Color ss_sp(const Math& m, Color d, float r) {  // substrate.rs:213-217
+    Color e1 = m.exp(col(-r / d.r, -r / d.g, -r / d.b));
+    Color e2 = m.exp(col(-r / d.r, -r / d.g, -r / d.b) / 3.0f);
+    return ((e1 + e2) * SPT_FRAC_1_PI) / ((8.0f * d) * r);
+}
+// what BxdfInputs adds for the BSSRDF (bxdf/mod.rs:62-67) and what BxdfSubsurfaceSample hands back (mod.rs:69-74)
+struct SubsurfaceIo {
+    const Ctx* cx = nullptr;
+    Vec3 po{0, 0, 0};
+    Coordinate coord_po;
+    bool has = false;
+    Vec3 pi{0, 0, 0};
+    Coordinate coord_pi;
+    Color sp{0, 0, 0};
+    float pdf_pi = 0.0f;
+};
+// Subsurface::sample up to the diffuse lobe: false = the probe found nothing (wi = 0, bxdf = 0, pdf = 1)
+bool subsurface_probe(const spt_material& mt, Rng& rng, SubsurfaceIo& io) {
+    const Ctx& cx = *io.cx;
+    float rand_u = rng.uniform_1d();
+    float rand_x, rand_y;
+    rng.uniform_2d(&rand_x, &rand_y);
+    Vec3 pt = io.coord_po.to_world(v3(1, 0, 0)), pb = io.coord_po.to_world(v3(0, 1, 0)), pn = io.coord_po.to_world(v3(0, 0, 1));
+    Vec3 st, sb, sn;
+    if (rand_u < 0.5f) { rand_u = rand_u * 2.0f; st = pt; sb = pb; sn = pn; }
+    else if (rand_u < 0.75f) { rand_u = rand_u * 4.0f - 2.0f; st = pb; sb = pn; sn = pt; }
+    else { rand_u = rand_u * 4.0f - 3.0f; st = pn; sb = pt; sn = pb; }
+    Color d = col(mt.c1);
+    float sp_d;
+    if (rand_u < 1.0f / 3.0f) { rand_u = 3.0f * rand_u; sp_d = d.r; }
+    else if (rand_u < 2.0f / 3.0f) { rand_u = 3.0f * rand_u - 1.0f; sp_d = d.g; }
+    else { rand_u = 3.0f * rand_u - 2.0f; sp_d = d.b; }
+    float sample_r = ss_sample_r(rand_x) * sp_d;
+    float r_max = ss_cdf_table().x[SPT_SS_CDF_SIZE - 1] * sp_d;
+    if (sample_r < 0.0f) return false;
+    float pihi = 2.0f * SPT_PI * rand_y;
+    float pihi_cos = cx.m.cos(pihi), pihi_sin = cx.m.sin(pihi);
+    float sample_l = spt_sqrt(r_max * r_max + sample_r * sample_r);
+    Vec3 start_p = ((io.po + (st * pihi_cos) * sample_r) + (sb * pihi_sin) * sample_r) + sn * sample_l;
+    Ray ray = make_ray(start_p, -sn);
+    // the reference loops "until nothing is hit", but it re-uses `inter`, whose t bounds the next search from ABOVE
+    // while t_min moves to just behind it: at most ONE intersection is ever collected (substrate.rs:280-291)
+    Inter inter;
+    inter.t = 2.0f * sample_l;
+    if (!aggregate_intersect(cx, ray, inter)) return false;
+    const spt_instance& in = cx.d->instances[inter.instance];
+    const spt_surface& surf = cx.d->surfaces[in.surface];
+    Coordinate coord_temp = surface_coord(cx, surf, ray, inter);
+    Vec3 pi = point_at(ray, inter.t);
+    Vec3 sample_normal = inter.normal;
+    // sample_inter = min((rand_u * 1) as usize, 0) = 0
+    Color sp = ss_sp(cx.m, d, length(pi - io.po));
+    Vec3 offset = io.coord_po.to_local(pi - io.po);
+    Vec3 nl = io.coord_po.to_local(sample_normal);
+    float r_xy = spt_sqrt(offset.x * offset.x + offset.y * offset.y);
+    float r_yz = spt_sqrt(offset.y * offset.y + offset.z * offset.z);
+    float r_zx = spt_sqrt(offset.z * offset.z + offset.x * offset.x);
+    float pdf_xy = 0.5f * spt_abs(nl.z) * avg(ss_sp(cx.m, d, r_xy));
+    float pdf_yz = 0.25f * spt_abs(nl.x) * avg(ss_sp(cx.m, d, r_yz));
+    float pdf_zx = 0.25f * spt_abs(nl.y) * avg(ss_sp(cx.m, d, r_zx));
+    io.has = true;
+    io.pi = pi;
+    io.coord_pi = coord_temp;
+    io.sp = sp;
+    io.pdf_pi = ((pdf_xy + pdf_yz) + pdf_zx) / 1.0f;
+    return true;
+}
+
+BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng, SubsurfaceIo* ss = nullptr) {
     BxdfSample s;
     switch (mt.bxdf) {
     case SPT_BXDF_LAMBERT: {  // src/bxdf/lambert.rs:20-36 + rng.rs:72-80
@@ -1005,24 +1105,31 @@ BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng)
             s.bxdf = specular_bxdf + substrate_bxdf;
             s.pdf = specular_pdf + sub_pdf;
         } else {
-            // substrate.sample: cosine hemisphere (Lambert::sample / Diffuse::sample)
-            float rx, ry;
-            rng.uniform_2d(&rx, &ry);
-            float phi = rx * 2.0f * SPT_PI;
-            float sp, cp;
-            m.sincos(phi, &sp, &cp);
-            float sin_theta = spt_sqrt(ry);
-            float cos_theta = spt_sqrt(1.0f - ry);
-            Vec3 wi = v3(sin_theta * cp, sin_theta * sp, cos_theta);
-            if (wo.z < 0.0f) wi.z = -wi.z;
-            Color samp_bxdf;
-            if (mt.substrate == SPT_SUBSTRATE_DIFFUSE) {
-                float fi = fresnel_n(mt.ior, wi, v3(0, 0, 1));
-                samp_bxdf = (1.0f - fi) * col(mt.c2);
-            } else {
-                samp_bxdf = col(mt.c0) * SPT_FRAC_1_PI;
+            // substrate.sample: cosine hemisphere (Lambert::sample / Diffuse::sample); Subsurface::sample first places
+            // the exit point with a probe ray (3 draws) and hands back an all-zero sample when that finds nothing
+            Vec3 wi = v3(0, 0, 0);
+            Color samp_bxdf = gray(0.0f);
+            float samp_pdf = 1.0f;
+            bool probe_ok = true;
+            if (mt.substrate == SPT_SUBSTRATE_SUBSURFACE) probe_ok = ss != nullptr && subsurface_probe(mt, rng, *ss);
+            if (probe_ok) {
+                float rx, ry;
+                rng.uniform_2d(&rx, &ry);
+                float phi = rx * 2.0f * SPT_PI;
+                float sp, cp;
+                m.sincos(phi, &sp, &cp);
+                float sin_theta = spt_sqrt(ry);
+                float cos_theta = spt_sqrt(1.0f - ry);
+                wi = v3(sin_theta * cp, sin_theta * sp, cos_theta);
+                if (wo.z < 0.0f) wi.z = -wi.z;
+                if (mt.substrate != SPT_SUBSTRATE_LAMBERT) {
+                    float fi = fresnel_n(mt.ior, wi, v3(0, 0, 1));
+                    samp_bxdf = (1.0f - fi) * col(mt.c2);
+                } else {
+                    samp_bxdf = col(mt.c0) * SPT_FRAC_1_PI;
+                }
+                samp_pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
             }
-            float samp_pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
             float sub_pdf = (1.0f - reflect_pdf) * samp_pdf;
             Color substrate_bxdf = (gray(1.0f) - fresnel_macro) * samp_bxdf;
             Color specular_bxdf;
@@ -1568,7 +1675,14 @@ Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
             }
 
             Vec3 wo = coord_po.to_local(-ray.direction);
-            BxdfSample samp = bxdf_sample(cx.m, mt, wo, rng);
+            SubsurfaceIo ss;
+            ss.cx = &cx; ss.po = po; ss.coord_po = coord_po;
+            BxdfSample samp = bxdf_sample(cx.m, mt, wo, rng, &ss);
+            if (ss.has) {  // pt.rs:147-151
+                po = ss.pi;
+                coord_po = ss.coord_pi;
+                throughput = throughput * (ss.sp / ss.pdf_pi);
+            }
 
             Color li = gray(0.0f);
             lsi_position = po;
@@ -1833,6 +1947,13 @@ void oracle_calc_differential(const float* ray18, const float* hit10, float duvd
     calc_differential(it, r);
     duvdx[0] = it.duvdx[0]; duvdx[1] = it.duvdx[1]; duvdy[0] = it.duvdy[0]; duvdy[1] = it.duvdy[1];
 }
+// Subsurface substrate seams (substrate.rs:187-229): diffusion profile Sp(r) for d, radius sampling, table entry
+void oracle_ss_sp(const float d[3], float r, float out[3]) {
+    Color c = ss_sp(Math{false}, col(d), r);
+    out[0] = c.r; out[1] = c.g; out[2] = c.b;
+}
+float oracle_ss_sample_r(float rand) { return ss_sample_r(rand); }
+void oracle_ss_cdf(uint32_t i, float xy[2]) { xy[0] = ss_cdf_table().x[i]; xy[1] = ss_cdf_table().y[i]; }
 void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out) {
     spt_rng r = spt_rng_seed(seed, pixel, sample);
     for (uint32_t i = 0; i < n; ++i) out[i] = spt_rng_f32(&r);

@@ -52,6 +52,10 @@ void oracle_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, flo
  * calc_differential (ray + aux ray = 18 floats, hit t/normal/tangent/bitangent = 10 floats) */
 int oracle_tex_eval(const spt_scene_desc* desc, uint32_t flags, uint32_t node, uint32_t n, const float* in, float* rgba);
 void oracle_calc_differential(const float* ray18, const float* hit10, float duvdx[2], float duvdy[2]);
+/* Subsurface substrate seams (src/bxdf/substrate.rs:187-229) */
+void oracle_ss_sp(const float d[3], float r, float out[3]);
+float oracle_ss_sample_r(float rand);
+void oracle_ss_cdf(uint32_t i, float xy[2]);
 void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 uint64_t oracle_rng_state(uint64_t seed, uint32_t pixel, uint32_t sample);
 void oracle_r2_offsets(uint32_t pixel, uint32_t spp, uint32_t n, float* out);

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 4
+SPT_ABI_VERSION = 5
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {

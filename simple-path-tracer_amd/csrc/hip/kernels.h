@@ -303,6 +303,8 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // kFeat 0 = kSimple, 1 = the general path.
 // kFeat 2 (textured): some material parameter, normal map or emissive map is an image texture; adds
 // texcoords, the camera ray differentials of bounce 0 and the per-hit material evaluation.
+// kFeat 3: 2 + the Subsurface substrate (a closest-hit probe inside mat_sample; 265 VGPRs = 1 wave / SIMD, which
+// is why it is a level of its own and not part of 2).
 // kFused (scenes whose traversal geometry is LDS-resident): the shadow ray and the extension ray are traced
 // right here instead of going through the shadow / extend queues and kernels.  The shade queue is dense,
 // so the waves are as full for the two traversals as they would be in k_shadow / k_extend, and the
@@ -313,7 +315,7 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // general kernel of any scene whose geometry + tables fit LDS.
 template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
-    constexpr bool kSimple = kFeat == 0, kTex = kFeat == 2;
+    constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3;
     if (kFused || kTab) stage_geometry<true>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
@@ -517,7 +519,21 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         rad_add(rc, slot, (thr * le) * weight);
                     }
                     f3 wo = coord.to_local(-ray.d);
-                    DBxdfSample samp = mat_sample(mt, wo, rng);
+                    DBxdfSample samp;
+                    if (kSubsurface) {   // Subsurface substrate: the BSSRDF probe ray is traced right here
+                        DSubsurfaceIo ssio;
+                        ssio.has = false;
+                        ssio.po = po;
+                        ssio.coord_po = coord;
+                        samp = mat_sample<true, kTab, kTab>(mt, wo, rng, &sc, &ssio);
+                        if (ssio.has) {  // pt.rs:147-151
+                            po = ssio.pi;
+                            coord = ssio.coord_pi;
+                            thr = thr * crcp(ssio.sp, ssio.pdf_pi);
+                        }
+                    } else {
+                        samp = mat_sample(mt, wo, rng);
+                    }
                     lsi = po;
                     if (!mat_is_delta(mt)) {
                         DLightSample ls;

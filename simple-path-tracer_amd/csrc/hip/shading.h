@@ -556,6 +556,21 @@ SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
         d.substrate = SPT_SUBSTRATE_LAMBERT;
         break;
     }
+    case SPT_MAT_SUBSURFACE: {  // material/subsurface.rs:66-93, bxdf::Subsurface::new (substrate.rs:199-211)
+        f3 albedo = tex_color(sc, r0.y, in);
+        float ld = tex_float(sc, r0.z, in, SPT_CHAN_R);
+        d.ior = ior;
+        d.bxdf = specular ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+        d.fresnel = SPT_FRESNEL_DIELECTRIC;
+        d.substrate = SPT_SUBSTRATE_SUBSURFACE;
+        d.c0 = albedo;
+        float fdr = 2.0f * fresnel_moment1(1.0f / ior);
+        d.c2 = cdiv(albedo * SPT_FRAC_1_PI, ((gray(1.0f) - albedo * fdr) * ior) * ior);
+        f3 q = albedo - gray(0.33f);
+        f3 q2 = q * q;
+        d.c1 = mk3(ld / (3.5f + 100.0f * (q2.x * q2.x)), ld / (3.5f + 100.0f * (q2.y * q2.y)), ld / (3.5f + 100.0f * (q2.z * q2.z)));
+        break;
+    }
     default:  // pbr_specular.rs:60-92
         d.c0 = tex_color(sc, r0.y, in);
         d.c1 = tex_color(sc, r0.z, in);
@@ -583,7 +598,7 @@ SPT_DEV f3 plastic_fresnel(const DMat& m, f3 i, f3 n) {
 SPT_DEV float substrate_pdf(f3 wo, f3 wi) { return (wo.z * wi.z >= 0.0f) ? spt_abs(wi.z) * SPT_FRAC_1_PI : 1.0f; }
 SPT_DEV f3 substrate_eval(const DMat& m, f3 wo, f3 wi) {
     if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
-    if (m.substrate == SPT_SUBSTRATE_DIFFUSE) return m.c2 * (1.0f - fresnel_n(m.ior, wi, mk3(0, 0, 1)));
+    if (m.substrate != SPT_SUBSTRATE_LAMBERT) return m.c2 * (1.0f - fresnel_n(m.ior, wi, mk3(0, 0, 1)));   // Diffuse, Subsurface::diffuse
     return m.c0 * SPT_FRAC_1_PI;
 }
 SPT_DEV float ndf_visible(const DMat& m, f3 wo, f3 wi, f3 h) {  // microfacet.rs:47-53
@@ -596,7 +611,86 @@ struct DBxdfSample {
     bool transmit;
 };
 
-SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng) {
+// ---- Subsurface substrate (src/bxdf/substrate.rs:182-350): k_shade<2> only -----------------------------
+// what BxdfInputs adds for the BSSRDF (bxdf/mod.rs:62-67) and what BxdfSubsurfaceSample hands back (mod.rs:69-74)
+struct DSubsurfaceIo {
+    f3 po;
+    DCoord coord_po;
+    bool has;
+    f3 pi;
+    DCoord coord_pi;
+    f3 sp;
+    float pdf_pi;
+};
+SPT_DEV float ss_sample_r(const DScene& sc, float rand) {  // substrate.rs:219-229 (first entry with y >= rand)
+    uint32_t lo = 1u, hi = SPT_SS_CDF_SIZE;   // the table is non-decreasing (checked when it is built): lower bound
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sc.ss_cdf[mid].y >= rand) hi = mid; else lo = mid + 1u;
+    }
+    if (lo >= SPT_SS_CDF_SIZE) return -1.0f;
+    const float2 a = sc.ss_cdf[lo - 1u], b = sc.ss_cdf[lo];
+    const float w = (rand - a.y) / (b.y - a.y);
+    return b.x * w + a.x * (1.0f - w);
+}
+SPT_DEV f3 ss_sp(f3 d, float r) {  // substrate.rs:213-217
+    const f3 q = mk3(-r / d.x, -r / d.y, -r / d.z);
+    const f3 e1 = cexp(q), e2 = cexp(crcp(q, 3.0f));
+    return cdiv((e1 + e2) * SPT_FRAC_1_PI, (d * 8.0f) * r);
+}
+// Subsurface::sample up to the diffuse lobe: false = the probe found nothing (wi = 0, bxdf = 0, pdf = 1).  The
+// reference's "collect every intersection" loop re-uses `inter`, whose t bounds the next search from above while
+// t_min moves to just behind it, so at most ONE intersection is ever collected (substrate.rs:280-291).
+template <bool kGeoLds, bool kL>
+SPT_DEV bool subsurface_probe(const DScene& sc, const DMat& m, DRng& rng, DSubsurfaceIo& io) {
+    float rand_u = rng.next();
+    const float rand_x = rng.next(), rand_y = rng.next();
+    const f3 pt = io.coord_po.to_world(mk3(1, 0, 0)), pb = io.coord_po.to_world(mk3(0, 1, 0)), pn = io.coord_po.to_world(mk3(0, 0, 1));
+    f3 st, sb, sn;
+    if (rand_u < 0.5f) { rand_u = rand_u * 2.0f; st = pt; sb = pb; sn = pn; }
+    else if (rand_u < 0.75f) { rand_u = rand_u * 4.0f - 2.0f; st = pb; sb = pn; sn = pt; }
+    else { rand_u = rand_u * 4.0f - 3.0f; st = pn; sb = pt; sn = pb; }
+    const f3 d = m.c1;
+    float sp_d;
+    if (rand_u < 1.0f / 3.0f) { rand_u = 3.0f * rand_u; sp_d = d.x; }
+    else if (rand_u < 2.0f / 3.0f) { rand_u = 3.0f * rand_u - 1.0f; sp_d = d.y; }
+    else { rand_u = 3.0f * rand_u - 2.0f; sp_d = d.z; }
+    const float sample_r = ss_sample_r(sc, rand_x) * sp_d;
+    const float r_max = sc.ss_cdf[SPT_SS_CDF_SIZE - 1].x * sp_d;
+    if (sample_r < 0.0f) return false;
+    const float pihi = 2.0f * SPT_PI * rand_y;
+    const float pihi_cos = spt_cos(pihi), pihi_sin = spt_sin(pihi);
+    const float sample_l = spt_sqrt(r_max * r_max + sample_r * sample_r);
+    DRay ray;
+    ray.o = ((io.po + (st * pihi_cos) * sample_r) + (sb * pihi_sin) * sample_r) + sn * sample_l;
+    ray.d = -sn;
+    ray.t_min = kTMinEps;
+    const DHit h = trace_closest<kGeoLds>(sc, ray, 2.0f * sample_l);
+    if (h.inst < 0) return false;
+    const DInter it = reconstruct_hit<true, kL>(sc, ray, h);
+    const spt_surface sf = load_surface<kL>(sc, it.surface);
+    const DCoord coord_temp = surface_coord<true>(sc, sf, ray, it);
+    const f3 pi = it.position;
+    const f3 sp = ss_sp(d, length(pi - io.po));
+    const f3 offset = io.coord_po.to_local(pi - io.po);
+    const f3 nl = io.coord_po.to_local(it.normal);
+    const float r_xy = spt_sqrt(offset.x * offset.x + offset.y * offset.y);
+    const float r_yz = spt_sqrt(offset.y * offset.y + offset.z * offset.z);
+    const float r_zx = spt_sqrt(offset.z * offset.z + offset.x * offset.x);
+    const float pdf_xy = 0.5f * spt_abs(nl.z) * cavg(ss_sp(d, r_xy));
+    const float pdf_yz = 0.25f * spt_abs(nl.x) * cavg(ss_sp(d, r_yz));
+    const float pdf_zx = 0.25f * spt_abs(nl.y) * cavg(ss_sp(d, r_zx));
+    io.has = true;
+    io.pi = pi;
+    io.coord_pi = coord_temp;
+    io.sp = sp;
+    io.pdf_pi = ((pdf_xy + pdf_yz) + pdf_zx) / 1.0f;
+    return true;
+}
+
+// kSS: Subsurface substrates can occur (k_shade<2>); sc / io are only touched then
+template <bool kSS = false, bool kGeoLds = false, bool kL = false>
+SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc = nullptr, DSubsurfaceIo* io = nullptr) {
     DBxdfSample s;
     s.transmit = false;
     switch (m.bxdf) {
@@ -706,18 +800,25 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng) {
             s.f = specular_bxdf + substrate_bxdf;
             s.pdf = specular_pdf + sub_pdf;
         } else {
-            float rx = rng.next(), ry = rng.next();
-            float phi = rx * 2.0f * SPT_PI;
-            float sp, cp;
-            spt_sincos(phi, &sp, &cp);
-            float sin_theta = spt_sqrt(ry);
-            float cos_theta = spt_sqrt(1.0f - ry);
-            f3 wi = mk3(sin_theta * cp, sin_theta * sp, cos_theta);
-            if (wo.z < 0.0f) wi.z = -wi.z;
-            f3 samp_bxdf;
-            if (m.substrate == SPT_SUBSTRATE_DIFFUSE) samp_bxdf = m.c2 * (1.0f - fresnel_n(m.ior, wi, mk3(0, 0, 1)));
-            else samp_bxdf = m.c0 * SPT_FRAC_1_PI;
-            float samp_pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
+            // substrate.sample: cosine hemisphere; Subsurface::sample first places the exit point with a probe ray
+            // (3 draws) and hands back an all-zero sample when that finds nothing
+            f3 wi = mk3(0, 0, 0), samp_bxdf = mk3(0, 0, 0);
+            float samp_pdf = 1.0f;
+            bool probe_ok = true;
+            if (kSS && m.substrate == SPT_SUBSTRATE_SUBSURFACE) probe_ok = subsurface_probe<kGeoLds, kL>(*sc, m, rng, *io);
+            if (probe_ok) {
+                float rx = rng.next(), ry = rng.next();
+                float phi = rx * 2.0f * SPT_PI;
+                float sp, cp;
+                spt_sincos(phi, &sp, &cp);
+                float sin_theta = spt_sqrt(ry);
+                float cos_theta = spt_sqrt(1.0f - ry);
+                wi = mk3(sin_theta * cp, sin_theta * sp, cos_theta);
+                if (wo.z < 0.0f) wi.z = -wi.z;
+                if (m.substrate != SPT_SUBSTRATE_LAMBERT) samp_bxdf = m.c2 * (1.0f - fresnel_n(m.ior, wi, mk3(0, 0, 1)));
+                else samp_bxdf = m.c0 * SPT_FRAC_1_PI;
+                samp_pdf = spt_abs(wi.z) * SPT_FRAC_1_PI;
+            }
             float sub_pdf = (1.0f - reflect_pdf) * samp_pdf;
             f3 substrate_bxdf = (gray(1.0f) - fresnel_macro) * samp_bxdf;
             f3 specular_bxdf;

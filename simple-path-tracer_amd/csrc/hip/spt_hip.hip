@@ -462,6 +462,8 @@ struct spt_scene {
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
     bool lds_tables = false;  // the shading tables fit LDS behind the geometry (k_shade<.., kTab>)
     bool fused = false;     // k_shade<0, ., kFused> can run: lds_tables and a simple scene
+    bool subsurface = false;  // some material has a Subsurface substrate (k_shade<3, .>)
+    DeviceBuffer ss_cdf;
     bool textured = false;  // a material recipe, normal map or emissive map samples textures per hit (k_shade<2, .>)
     DeviceBuffer textures, tex_prog, tex_root, tex_chain, images, image_levels, texels, recipes;
     std::vector<hipEvent_t> events;
@@ -549,7 +551,7 @@ void validate(const spt_scene_desc& s) {
     }
     for (uint32_t i = 0; i < s.n_material_recipes; ++i) {
         const spt_material_recipe& r = s.material_recipes[i];
-        if (r.type > SPT_MAT_PBR_SPECULAR || r.rough_chan > SPT_CHAN_A || r.metal_chan > SPT_CHAN_A) fail(SPT_ERR_INVALID_ARG, "scene desc: bad material recipe");
+        if (r.type > SPT_MAT_SUBSURFACE || r.rough_chan > SPT_CHAN_A || r.metal_chan > SPT_CHAN_A) fail(SPT_ERR_INVALID_ARG, "scene desc: bad material recipe");
         for (int k = 0; k < 4; ++k)
             if (r.tex[k] >= s.n_textures) fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe texture out of range");
     }
@@ -820,6 +822,18 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         bool textured = false;
         for (uint32_t i = 0; i < s.n_materials; ++i) textured = textured || s.materials[i].recipe != 0;
         for (uint32_t i = 0; i < s.n_surfaces; ++i) textured = textured || s.surfaces[i].normal_map != 0 || s.surfaces[i].emissive_map != 0;
+        for (uint32_t i = 0; i < s.n_materials; ++i) sc->subsurface = sc->subsurface || s.materials[i].substrate == SPT_SUBSTRATE_SUBSURFACE;
+        for (uint32_t i = 0; i < s.n_material_recipes; ++i) sc->subsurface = sc->subsurface || s.material_recipes[i].type == SPT_MAT_SUBSURFACE;
+        if (sc->subsurface) {
+            textured = true;   // k_shade<3> is k_shade<2> + the probe: the texture tables (possibly empty) are uploaded below
+            std::vector<float2> cdf(SPT_SS_CDF_SIZE);
+            for (uint32_t i = 0; i < SPT_SS_CDF_SIZE; ++i) {
+                spt_ss_cdf_entry(i, &cdf[i].x, &cdf[i].y);
+                if (i && !(cdf[i].y >= cdf[i - 1].y)) fail(SPT_ERR_UNSUPPORTED, "BSSRDF radius table is not monotonic");   // ss_sample_r bisects it
+            }
+            sc->ss_cdf.upload(cdf.data(), cdf.size());
+            d.ss_cdf = sc->ss_cdf.as<float2>();
+        }
         sc->textured = textured;
         if (textured) {
             simple = false;
@@ -1177,15 +1191,16 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     continue;
                 }
                 const bool tab = sc->lds_tables && std::getenv("SPT_NO_LDS_TABLES") == nullptr;   // shading tables from LDS (tab_ld)
+                const size_t shade_lds = sc->subsurface ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3>: traversal stack
 #define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
     if (tab) {                                                                                                                                 \
         if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
         else hipLaunchKernelGGL((k_shade<FEAT, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);              \
     } else {                                                                                                                                   \
-        if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);                       \
-        else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, rc, b);                             \
+        if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);               \
+        else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);                     \
     }
-                if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else { SPT_LAUNCH_SHADE(2) }
+                if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) } else { SPT_LAUNCH_SHADE(3) }
 #undef SPT_LAUNCH_SHADE
                 end();
                 // k_shadow(b) and k_extend(b) are independent unless the scene has an environment (then a missing

@@ -62,6 +62,7 @@ struct DScene {
     const uint4* image_levels;     // (width, height, first_texel, -)
     const uint32_t* texels;        // RGBA8
     const uint4* recipes;          // 2 x uint4 per spt_material_recipe
+    const float2* ss_cdf;          // SPT_SS_CDF_SIZE x (x, y): BSSRDF radius table (scenes with a Subsurface substrate)
 };
 
 struct DHit {

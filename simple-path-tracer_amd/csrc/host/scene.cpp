@@ -694,7 +694,29 @@ struct SceneBuilder {
             m.substrate = SPT_SUBSTRATE_LAMBERT;
             m.c0[0] = diffuse.x; m.c0[1] = diffuse.y; m.c0[2] = diffuse.z;
             m.c1[0] = specular.x; m.c1[1] = specular.y; m.c1[2] = specular.z;
-        } else if (ty == "pndf_conductor" || ty == "pndf_plastic" || ty == "subsurface") {
+        } else if (ty == "subsurface") {
+            // src/material/subsurface.rs:66-93: roughness squared; bxdf::Subsurface::new (substrate.rs:199-211) over a
+            // dielectric-Fresnel coat
+            float int_ior = p.get_float("int_ior");
+            float ext_ior = p.get_float_or("ext_ior", 1.0f);
+            V3 albedo = texture(p.get_str("albedo"));
+            float ld = texture(p.get_str("ld")).x;
+            roughness(m.ax, m.ay);
+            m.ior = int_ior / ext_ior;
+            m.bxdf = (m.ax < 0.0001f || m.ay < 0.0001f) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+            m.fresnel = SPT_FRESNEL_DIELECTRIC;
+            m.substrate = SPT_SUBSTRATE_SUBSURFACE;
+            m.c0[0] = albedo.x; m.c0[1] = albedo.y; m.c0[2] = albedo.z;
+            float fdr = 2.0f * fresnel_moment1(1.0f / m.ior);
+            V3 num = albedo * 0.318309886183790671538f;
+            V3 den = ((V3{1, 1, 1} - albedo * fdr) * m.ior) * m.ior;
+            m.c2[0] = num.x / den.x; m.c2[1] = num.y / den.y; m.c2[2] = num.z / den.z;
+            const float a[3] = {albedo.x, albedo.y, albedo.z};
+            for (int k = 0; k < 3; ++k) {
+                float q = a[k] - 0.33f, q2 = q * q;   // powi(4)
+                m.c1[k] = ld / (3.5f + 100.0f * (q2 * q2));
+            }
+        } else if (ty == "pndf_conductor" || ty == "pndf_plastic") {
             throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)");
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
@@ -722,6 +744,7 @@ struct SceneBuilder {
             else if (ty == "plastic") { r.type = SPT_MAT_PLASTIC; slot(0, "albedo"); rough_slots(); }
             else if (ty == "pbr_metallic") { r.type = SPT_MAT_PBR_METALLIC; slot(0, "base_color"); slot(1, "metallic"); rough_slots(); }
             else if (ty == "pbr_specular") { r.type = SPT_MAT_PBR_SPECULAR; slot(0, "diffuse"); slot(1, "specular"); rough_slots(); }
+            else if (ty == "subsurface") { r.type = SPT_MAT_SUBSURFACE; slot(0, "albedo"); slot(1, "ld"); rough_slots(); }
             if (textured) {
                 hs.material_recipes.push_back(r);
                 m.recipe = (uint32_t)hs.material_recipes.size();

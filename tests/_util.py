@@ -97,6 +97,12 @@ def oracle_lib():
         lib.oracle_tex_eval.argtypes = [C.POINTER(spt.SceneDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.oracle_calc_differential.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.oracle_calc_differential.restype = None
+        lib.oracle_ss_sp.argtypes = [C.c_float * 3, C.c_float, C.c_float * 3]
+        lib.oracle_ss_sp.restype = None
+        lib.oracle_ss_sample_r.argtypes = [C.c_float]
+        lib.oracle_ss_sample_r.restype = C.c_float
+        lib.oracle_ss_cdf.argtypes = [C.c_uint32, C.c_float * 2]
+        lib.oracle_ss_cdf.restype = None
         _oracle = lib
     return _oracle
 

@@ -20,6 +20,7 @@ CASES = [  # name, scene, camera, sampler, spp, (w, h), seed
     ("film_t_plastic", "t_plastic.json", None, "random", 16, (64, 48), 1),
     ("film_t_textured", "t_textured.json", None, "recurrence", 16, (64, 48), 1),
     ("film_t_gltf", "t_gltf.gltf", "cam", "random", 16, (64, 48), 1),
+    ("film_t_subsurface", "t_subsurface.json", None, "random", 16, (64, 48), 1),
 ]
 
 

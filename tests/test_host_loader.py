@@ -73,7 +73,7 @@ def test_missing_and_mistyped_fields_fail_like_the_reference(tmp_path):
 
 
 def test_out_of_scope_features_are_reported_not_ignored(tmp_path):
-    for mutate in (lambda s: s["materials"].append({"type": "subsurface", "name": "p"}),
+    for mutate in (lambda s: s["materials"].append({"type": "pndf_conductor", "name": "p"}),
                    lambda s: s["primitives"].append({"type": "catmull_clark", "name": "cc", "ply_file": "x.ply"})):
         bad = json.loads(json.dumps(BASE))
         mutate(bad)
