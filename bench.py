@@ -134,6 +134,7 @@ def main():
         dist.broadcast_object_list(name, src=0)
         if rank != 0:
             film = spt.SharedFilm(args.height, args.width, name=name[0])
+        film.pin()
 
     kernel_ms = np.zeros(spt.N_KERNELS)
     kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
@@ -141,19 +142,17 @@ def main():
 
     def step(profiled):
         nonlocal stats_last
+        # N > 1: every rank's strips are DMA-ed straight into the node's shared-memory film (no collective, no host-side
+        # scatter); N = 1: the pinned shard buffer is the image
         shard = renderer.render_shard(scene, cfg, device=local_rank, shard_index=rank, shard_count=world,
                                       strip_rows=strip_rows, samples_per_pass=args.samples_per_pass,
-                                      profile=profiled, reuse_output=True)
+                                      profile=profiled, reuse_output=True, film=film.film if film is not None else None)
         st = renderer.last_stats
         if profiled:
             for k in range(spt.N_KERNELS):
                 kernel_ms[k] += st.kernel_ms[k]
                 kernel_launches[k] += st.kernel_launches[k]
         stats_last = st
-        # image assembly: every rank writes its (disjoint) rows into the node's shared-memory film - no
-        # collective on the data path
-        if film is not None:
-            film.write_shard(shard, rank, world, strip_rows)
         return shard
 
     for _ in range(args.warmup):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 5
+#define SPT_ABI_VERSION 6
 
 typedef int32_t spt_status;
 enum {
@@ -292,6 +292,10 @@ typedef struct spt_render_params {
     uint32_t shard_index, shard_count, strip_rows;
     uint32_t samples_per_pass;     /* tuning: spp rendered per wavefront pass (0 = default) */
     uint32_t flags;                /* SPT_RENDER_* */
+    uint64_t out_strip_stride;     /* bytes between the starts of consecutive strips of THIS shard in rgb_mean_out;
+                                      0 = packed (strip_rows * width * 12).  shard_count * strip_rows * width * 12 with
+                                      rgb_mean_out pointing at the shard's first row inside a full-image film makes every
+                                      rank write its rows in place (one strided DMA, no host-side scatter) */
 } spt_render_params;
 enum { SPT_RENDER_PROFILE = 1u /* time each kernel class with HIP events */ };
 
@@ -353,6 +357,10 @@ spt_status spt_trace_any(const spt_scene* scene, uint32_t n, const spt_ray* rays
  * pointer is accepted by spt_render. */
 spt_status spt_alloc_pinned(uint64_t bytes, void** out);
 void spt_free_pinned(void* p);
+/* page-lock / unlock caller memory (e.g. a shared-memory film mapped by every rank) so that spt_render's copy-out
+ * into it runs at DMA speed */
+spt_status spt_pin_host(void* p, uint64_t bytes);
+void spt_unpin_host(void* p);
 
 /* Test seam: evaluates one function of include/spt_detmath.h on the device (fn: 0 sin, 1 cos,
  * 2 log, 3 exp, 4 acos, 5 atan2(a,b), 6 asin, 7 round, 8 floor, 9 sqrt, 10 a/b, 11 max(a,b),

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 5
+SPT_ABI_VERSION = 6
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -159,7 +159,8 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
                 ("sampler", C.c_uint32), ("division_x", C.c_uint32), ("division_y", C.c_uint32),
                 ("seed", C.c_uint64), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
-                ("strip_rows", C.c_uint32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32)]
+                ("strip_rows", C.c_uint32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32),
+                ("out_strip_stride", C.c_uint64)]
 
 
 class RenderStats(C.Structure):
@@ -230,6 +231,9 @@ def hip_lib() -> C.CDLL:
         lib.spt_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
         lib.spt_free_pinned.argtypes = [C.c_void_p]
         lib.spt_free_pinned.restype = None
+        lib.spt_pin_host.argtypes = [C.c_void_p, C.c_uint64]
+        lib.spt_unpin_host.argtypes = [C.c_void_p]
+        lib.spt_unpin_host.restype = None
         lib.spt_debug_detmath.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip_lib = lib
     return _hip_lib
@@ -408,7 +412,7 @@ class PathTracer:
 
     def render_shard(self, scene: Scene, config: OutputConfig, device: int = 0, shard_index: int = 0,
                      shard_count: int = 1, strip_rows: int = 16, samples_per_pass: int = 0,
-                     profile: bool = False, reuse_output: bool = False) -> np.ndarray:
+                     profile: bool = False, reuse_output: bool = False, film: Optional[np.ndarray] = None) -> np.ndarray:
         """Mean radiance of this shard's rows, shape (rows, width, 3) f32, via the HIP path.
         reuse_output=True returns a page-locked buffer owned by the device scene that the next call
         with the same shape overwrites (no per-call allocation, DMA-speed copy-out)."""
@@ -418,6 +422,16 @@ class PathTracer:
                         RENDER_PROFILE if profile else 0)
         rows = C.c_uint32()
         _check_hip(hip_lib().spt_shard_rows(C.byref(p), C.byref(rows)))
+        if film is not None:
+            # write this shard's strips in place into a full-image (height, width, 3) f32 film (e.g. SharedFilm.film)
+            assert film.shape == (config.height, config.width, 3) and film.dtype == np.float32 and film.flags["C_CONTIGUOUS"]
+            row_bytes = config.width * 12
+            p.out_strip_stride = shard_count * strip_rows * row_bytes
+            stats = RenderStats()
+            first = film.ctypes.data + shard_index * strip_rows * row_bytes
+            _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), first if rows.value else film.ctypes.data, C.byref(stats)))
+            self.last_stats = stats
+            return film
         if reuse_output and rows.value:
             out = ds.film_buffer(rows.value, config.width)
         else:
@@ -549,8 +563,15 @@ class SharedFilm:
             except Exception:
                 pass
         self._owner = create
+        self._pinned = False
         self.name = self._shm.name
         self.film = np.ndarray((height, width, 3), dtype=np.float32, buffer=self._shm.buf)
+
+    def pin(self) -> None:
+        """Page-lock this process' mapping (spt_pin_host) so that render_shard(film=self.film) copies out at DMA speed."""
+        if not self._pinned:
+            _check_hip(hip_lib().spt_pin_host(self.film.ctypes.data, self.film.nbytes))
+            self._pinned = True
 
     def write_shard(self, shard: np.ndarray, rank: int, world: int, strip_rows: int) -> None:
         rows = shard_rows(self.height, rank, world, strip_rows)
@@ -565,6 +586,9 @@ class SharedFilm:
             k = e + 1
 
     def close(self) -> None:
+        if self._pinned:
+            hip_lib().spt_unpin_host(self.film.ctypes.data)
+            self._pinned = False
         self.film = None
         self._shm.close()
         if self._owner:

@@ -1255,7 +1255,21 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         hipLaunchKernelGGL(k_finish, dim3((n_pix * 3 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, sc->out.as<float>());
         end();
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(rgb_mean_out, sc->out.p, (size_t)n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        {
+            const size_t strip_bytes = (size_t)strip_rows * p.width * 3 * sizeof(float);
+            if (p.out_strip_stride == 0 || p.out_strip_stride == strip_bytes) {
+                HIP_CHECK(hipMemcpyAsync(rgb_mean_out, sc->out.p, (size_t)n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+            } else {
+                // strided copy-out: the shard's strips land strip by strip in a larger (full-image) film
+                if (p.out_strip_stride < strip_bytes) fail(SPT_ERR_INVALID_ARG, "render: out_strip_stride smaller than a strip");
+                const size_t full = rows / strip_rows, rest_rows = rows - full * strip_rows;
+                if (full)
+                    HIP_CHECK(hipMemcpy2DAsync(rgb_mean_out, p.out_strip_stride, sc->out.p, strip_bytes, strip_bytes, full, hipMemcpyDeviceToHost, st));
+                if (rest_rows)
+                    HIP_CHECK(hipMemcpyAsync((char*)rgb_mean_out + full * p.out_strip_stride, (const char*)sc->out.p + full * strip_bytes,
+                                             rest_rows * (size_t)p.width * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+            }
+        }
         HIP_CHECK(hipEventRecord(ev_total1, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (stats) {
@@ -1325,6 +1339,20 @@ spt_status spt_alloc_pinned(uint64_t bytes, void** out) {
     if (e != hipSuccess) { g_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); return SPT_ERR_OUT_OF_MEMORY; }
     return SPT_OK;
 }
+spt_status spt_pin_host(void* p, uint64_t bytes) {
+    if (!p || !bytes) { g_error = "pin_host: null argument"; return SPT_ERR_INVALID_ARG; }
+    if (usable_device_count() == 0) { g_error = "no HIP device is visible: libspt_hip has no CPU fallback"; return SPT_ERR_NO_DEVICE; }
+    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        g_error = "pin_host: hipHostRegister failed";
+        return SPT_ERR_OUT_OF_MEMORY;
+    }
+    return SPT_OK;
+}
+void spt_unpin_host(void* p) {
+    if (p) (void)hipHostUnregister(p);
+}
+
 void spt_free_pinned(void* p) {
     if (p) (void)hipHostFree(p);
 }

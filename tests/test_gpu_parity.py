@@ -200,6 +200,28 @@ def test_screen_space_bound_with_arbitrary_cameras(spt):
             assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan]), (scene_name, k)
 
 
+def test_shards_written_in_place_into_a_full_film(spt):
+    """out_strip_stride: three ranks' strips (the last one partial: 100 rows, strips of 16) DMA-ed straight into one
+    film = the single-shard render; also through a page-locked shared-memory film."""
+    sc = _scene(spt, "t_materials.json")
+    r = spt.PathTracer(max_depth=5, sampler=spt.SAMPLER_RANDOM, spp=6, seed=8)
+    cfg = spt.OutputConfig(72, 100, None, "main")
+    full = r.render_shard(sc, cfg)
+    film = np.full((100, 72, 3), -1.0, dtype=np.float32)
+    for k in range(3):
+        r.render_shard(sc, cfg, shard_index=k, shard_count=3, strip_rows=16, film=film)
+    assert np.array_equal(film.view(np.uint32), full.view(np.uint32))
+    shared = spt.SharedFilm(100, 72, create=True)
+    try:
+        shared.pin()
+        shared.film[:] = -1.0
+        for k in range(4):
+            r.render_shard(sc, cfg, shard_index=k, shard_count=4, strip_rows=8, film=shared.film)
+        assert np.array_equal(shared.film.view(np.uint32), full.view(np.uint32))
+    finally:
+        shared.close()
+
+
 def test_render_error_paths(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=4)
