@@ -316,9 +316,12 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3;
-    if (kFused || kTab) stage_geometry<true>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
+    // workgroups of an empty shard (most of them in the late bounces) leave before staging anything into LDS;
+    // a workgroup whose first item is past the end has nothing to do either (block-uniform, no barrier skipped)
+    if ((blockIdx.x / kShards) * blockDim.x >= n) return;
+    if (kFused || kTab) stage_geometry<true>(sc);
     uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
     uint32_t* ext_count = q_count(rc.counts, bounce, Q_EXT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
@@ -632,9 +635,10 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
 // ---------------------------------------------------------------------------- shadow
 template <bool kLds>
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
-    stage_geometry<kLds>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
+    if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
+    stage_geometry<kLds>(sc);
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
     for (uint32_t i = (blockIdx.x / kShards) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -649,9 +653,10 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_
 // ---------------------------------------------------------------------------- extend
 template <bool kLds>
 __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
-    stage_geometry<kLds>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
+    if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
+    stage_geometry<kLds>(sc);
     uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
