@@ -223,7 +223,7 @@ def main():
                           "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         dom_name = max(kern, key=lambda n: kern[n]["ms_per_step"]) if kern else "primary"
         dom = kern.get(dom_name, {"GBps": 0.0, "frac": 0.0, "avg_launch_ms": None, "alg_MB_per_launch": None})
-        pipeline_bytes = sum(alg.values())
+        pipeline_bytes = sum(alg[n] for n in kern)                     # only the kernel classes that ran (fused: no shadow / extend)
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected in a
         # separate rocprofv3 --pmc run of this same command and committed under profiles/ (tools/pmc_traffic.py)
         traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r01_traffic_bench.json")
