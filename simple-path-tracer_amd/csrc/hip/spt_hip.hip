@@ -125,6 +125,9 @@ struct SahTri {
     float lo[3], hi[3], c[3];
     uint32_t id;
 };
+void build_sah(std::vector<SahTri>& t, uint32_t tri_first, uint32_t max_leaf, float traversal_cost, std::vector<spt_bvh_node>& nodes,
+               std::vector<uint32_t>& order, const char* what);
+
 void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_count, std::vector<spt_bvh_node>& nodes,
                     std::vector<uint32_t>& order /* slot (absolute) -> ABI triangle index, filled for this mesh's range */) {
     std::vector<SahTri> t(tri_count);
@@ -137,12 +140,35 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
         }
         t[i].id = tri_first + i;
     }
-    constexpr int kBins = 32;
     // tuning knobs (defaults measured on cfg2 / cfg5; the environment overrides exist for that measurement only)
-    uint32_t kMaxLeaf = 4;
-    float kTraversalCost = 1.2f;   // one wide-node visit (two slab tests) relative to one triangle test
-    if (const char* v = std::getenv("SPT_BVH_MAX_LEAF")) kMaxLeaf = (uint32_t)std::min(15, std::max(1, std::atoi(v)));
-    if (const char* v = std::getenv("SPT_BVH_TRAVERSAL_COST")) kTraversalCost = (float)std::atof(v);
+    uint32_t max_leaf = 4;
+    float traversal_cost = 1.2f;   // one wide-node visit (two slab tests) relative to one triangle test
+    if (const char* v = std::getenv("SPT_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::min(15, std::max(1, std::atoi(v)));
+    if (const char* v = std::getenv("SPT_BVH_TRAVERSAL_COST")) traversal_cost = (float)std::atof(v);
+    build_sah(t, tri_first, max_leaf, traversal_cost, nodes, order, "BLAS");
+}
+
+// The same builder over the instances' world boxes: the device-side TLAS.  An instance visit (transform the ray, walk
+// a BLAS) costs far more than a node visit, so leaves hold one instance unless the split is useless.
+void build_sah_tlas(const spt_instance* inst, uint32_t n, std::vector<spt_bvh_node>& nodes, std::vector<uint32_t>& order) {
+    std::vector<SahTri> t(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            t[i].lo[k] = inst[i].bmin[k];
+            t[i].hi[k] = inst[i].bmax[k];
+            t[i].c[k] = 0.5f * (t[i].lo[k] + t[i].hi[k]);
+        }
+        t[i].id = i;
+    }
+    order.assign(n, 0u);
+    build_sah(t, 0u, 2u, 0.125f, nodes, order, "TLAS");
+}
+
+// items [0, t.size()) -> a tree appended to `nodes`; leaves index slots tri_first + k, order[slot] = item id
+void build_sah(std::vector<SahTri>& t, uint32_t tri_first, uint32_t kMaxLeaf, float kTraversalCost, std::vector<spt_bvh_node>& nodes,
+               std::vector<uint32_t>& order, const char* what) {
+    const uint32_t tri_count = (uint32_t)t.size();
+    constexpr int kBins = 32;
     auto half_area = [](const float* lo, const float* hi) {
         float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         return dx * dy + dy * dz + dz * dx;
@@ -250,7 +276,7 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
             if (nodes[k].b & SPT_LEAF_FLAG) { ++leaves; ++hist[std::min(15u, nodes[k].b & ~SPT_LEAF_FLAG)]; }
             else ++inner;
         }
-        std::fprintf(stderr, "[spt] device BLAS: %u triangles, %u inner nodes, %u leaves, leaf sizes 1:%u 2:%u 3:%u 4:%u >4:%u\n", tri_count, inner, leaves,
+        std::fprintf(stderr, "[spt] device %s: %u items, %u inner nodes, %u leaves, leaf sizes 1:%u 2:%u 3:%u 4:%u >4:%u\n", what, tri_count, inner, leaves,
                      hist[1], hist[2], hist[3], hist[4], leaves - hist[1] - hist[2] - hist[3] - hist[4]);
     }
 }
@@ -715,14 +741,21 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             std::vector<float4> wtlas;
             d.tlas_root = 0;
             for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = 0.0f; d.tlas_hi[k] = 0.0f; }
+            // TLAS leaf slot -> instance index: identity for the caller's tree (its leaves index the instance array) and
+            // for a GROUP aggregate, the leaf order of the device-built tree otherwise
+            std::vector<uint32_t> tlas_order(s.n_instances);
+            for (uint32_t i = 0; i < s.n_instances; ++i) tlas_order[i] = i;
             if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) {
-                const uint32_t sup = build_wide(s.tlas_nodes, 0, wtlas, 0xffffffffu, "tlas", own_bvh);
-                std::memcpy(&d.tlas_root, &wtlas[(size_t)sup * 4].w, 4);      // left child of the super-root = real root
-                for (int k = 0; k < 3; ++k) {
-                    const float pad = own_bvh ? box_pad(s.tlas_nodes[0].bmin[k], s.tlas_nodes[0].bmax[k]) : 0.0f;
-                    d.tlas_lo[k] = s.tlas_nodes[0].bmin[k] - pad;
-                    d.tlas_hi[k] = s.tlas_nodes[0].bmax[k] + pad;
+                std::vector<spt_bvh_node> own_tlas;
+                if (own_bvh && s.n_instances) {
+                    build_sah_tlas(s.instances, s.n_instances, own_tlas, tlas_order);   // boxes padded by the builder
+                    tlas_depth = bvh_depth(own_tlas.data(), (uint32_t)own_tlas.size(), 0, s.n_instances, "device tlas");
+                    if (tlas_depth + 2 > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "device TLAS deeper than the traversal stack (48 levels)");
                 }
+                const spt_bvh_node* tlas_src = own_tlas.empty() ? s.tlas_nodes : own_tlas.data();
+                const uint32_t sup = build_wide(tlas_src, 0, wtlas, 0xffffffffu, "tlas", false);
+                std::memcpy(&d.tlas_root, &wtlas[(size_t)sup * 4].w, 4);      // left child of the super-root = real root
+                for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = tlas_src[0].bmin[k]; d.tlas_hi[k] = tlas_src[0].bmax[k]; }
             }
             // BLAS: 2-wide full-precision nodes when the whole scene fits LDS, compressed 4-wide nodes otherwise
             // own binned-SAH BLAS per mesh (see build_sah_blas), or the ABI trees as they are
@@ -775,6 +808,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
                 d.o_blas = append(wblas.data(), wblas.size() * 16);
                 d.o_tri = append(tri_blob.data(), (size_t)s.n_tris * sizeof(spt_tri_pos));
+                d.o_tord = append(tlas_order.data(), tlas_order.size() * sizeof(uint32_t));
             };
             const size_t stack_bytes = (size_t)kLdsStack * 2 * kBlock * sizeof(uint32_t);   // (ref, t0) per LDS level
             assemble(false);

@@ -50,6 +50,7 @@ struct DScene {
     uint32_t o_tlas, o_inst, o_mesh, o_blas, o_tri, o_sph;
     // fused bounces only: the shading tables also sit in the staged blob (float4 offsets), see tab_ld
     uint32_t o_attr, o_surf, o_mat, o_light;
+    uint32_t o_tord;           // TLAS leaf slot -> instance index (the device-built TLAS re-orders its leaves)
     uint32_t fast_slab;        // device-built (padded) trees: box tests only cull, so 1/d may be v_rcp_f32 (1 ulp)
     uint32_t tlas_root;        // ref of the TLAS root (wide-node index or leaf ref)
     float tlas_lo[3], tlas_hi[3];  // its box
@@ -87,6 +88,12 @@ template <bool kLds>
 SPT_DEV float4 geo_ld_tri(const DScene& sc, uint32_t off) {
     if (kLds) return geo_lds(sc)[off];
     return sc.geo[off];
+}
+// instance index behind TLAS leaf slot `slot` (a GROUP aggregate walks the instances directly)
+template <bool kLds>
+SPT_DEV uint32_t tlas_instance(const DScene& sc, uint32_t slot) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(kLds ? geo_lds(sc) : const_cast<float4*>(sc.geo));
+    return p[4u * sc.o_tord + slot];
 }
 // once per workgroup, before any traversal
 template <bool kLds>
@@ -443,7 +450,7 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
         const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
         if (root_hit<true>(tlo, thi, ray.o, inv_w, ray.t_min, h.t))
         walk_tree<kLds, true, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
-            for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds>(sc, i, ray, h, st);
+            for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds>(sc, tlas_instance<kLds>(sc, i), ray, h, st);
             return false;
         });
     }
@@ -467,7 +474,7 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
     if (!root_hit<false>(tlo, thi, ray.o, inv_w, ray.t_min, t_max)) return false;
     return walk_tree<kLds, false, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i)
-            if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
+            if (instance_any<kLds>(sc, tlas_instance<kLds>(sc, i), ray, t_max, st)) return true;
         return false;
     });
 }
@@ -592,7 +599,7 @@ struct Walker {
         }
         // phase 0: next instance of the current leaf, else pop the TLAS stack
         if (inst_next < inst_end) {
-            inst = inst_next++;
+            inst = tlas_instance<kLds>(sc, inst_next++);   // slot -> instance (identity for a GROUP aggregate)
             uint32_t prim_type, prim_id;
             DRay wr;
             wr.o = o; wr.d = d; wr.t_min = t_min;

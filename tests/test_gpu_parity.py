@@ -222,6 +222,49 @@ def test_shards_written_in_place_into_a_full_film(spt):
         shared.close()
 
 
+def test_many_instances_device_tlas(spt, tmp_path):
+    """225 instances (cubes and spheres, random scales / rotations): the device-built TLAS (SAH over the instance
+    boxes, leaves re-ordered behind an index table) returns the exhaustive oracle's hits and film."""
+    import json
+    import shutil
+    os.makedirs(tmp_path / "models")
+    shutil.copy(os.path.join(_util.SCENES, "models", "cube.obj"), tmp_path / "models" / "cube.obj")
+    rng = np.random.default_rng(3)
+    inst = [{"name": "floor", "primitive": "cube", "material": "m", "scale": [12.0, 0.1, 12.0], "translate": [0.0, -1.2, 0.0]}]
+    for k in range(224):
+        x, z = (k % 15 - 7) * 1.4, (k // 15 - 7) * 1.4
+        sc = float(rng.uniform(0.15, 0.55))
+        inst.append({"name": "i%03d" % k, "primitive": "cube" if k % 3 else "ball", "material": "m" if k % 2 else "g",
+                     "scale": [sc, float(sc * rng.uniform(0.5, 2.0)), sc], "rotate": [float(rng.uniform(0, 90)), float(rng.uniform(0, 360)), 0.0],
+                     "translate": [x + float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.8, 1.5)), z + float(rng.uniform(-0.3, 0.3))]})
+    scene = {"cameras": {"type": "perspective", "name": "c", "eye": [0.0, 9.0, 16.0], "forward": [0.0, -0.5, -1.0], "up": [0.0, 1.0, 0.0], "fov": 40.0},
+             "textures": [{"type": "scalar", "name": "w", "value": [0.8, 0.8, 0.75]}, {"type": "scalar", "name": "gold_n", "value": [0.14, 0.37, 1.44]},
+                          {"type": "scalar", "name": "gold_k", "value": [3.98, 2.38, 1.6]}, {"type": "scalar", "name": "r", "value": [0.3, 0.3, 0.3]}],
+             "materials": [{"type": "lambert", "name": "m", "albedo": "w"},
+                           {"type": "conductor", "name": "g", "ior": "gold_n", "ior_k": "gold_k", "roughness": "r"}],
+             "mediums": [], "surfaces": [],
+             "primitives": [{"type": "trimesh", "name": "cube", "obj_file": "models/cube.obj"}, {"type": "sphere", "name": "ball", "radius": 1.0}],
+             "instances": inst,
+             "lights": [{"type": "directional", "name": "sun", "direction": [-0.4, -1.0, -0.3], "strength": [3.0, 2.9, 2.7]}],
+             "environment": {"type": "color", "color": [0.3, 0.35, 0.45]}}
+    path = tmp_path / "many.json"
+    path.write_text(json.dumps(scene))
+    sc = spt.load_scene(str(path))
+    assert sc.desc.n_instances == 225
+    rays = _util.random_rays(sc, 100_000, seed=9)
+    ref = _util.oracle_trace_closest(sc, rays, _util.device_oracle_flags())
+    got = sc.device_scene(0).trace_closest(rays)
+    assert (ref["instance"] >= 0).mean() > 0.3
+    assert ref.tobytes() == got.tobytes()
+    r = spt.PathTracer(max_depth=6, sampler=spt.SAMPLER_RANDOM, spp=8, seed=2)
+    w, h = 200, 150
+    ref_film, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags())
+    film = r.render_shard(sc, spt.OutputConfig(w, h))
+    nan = np.isnan(ref_film)
+    assert nan.mean() < 1e-3 and np.array_equal(nan, np.isnan(film))
+    assert np.array_equal(film.view(np.uint32)[~nan], ref_film.view(np.uint32)[~nan])
+
+
 def test_render_error_paths(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=4)
