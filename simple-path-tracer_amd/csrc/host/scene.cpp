@@ -386,6 +386,9 @@ struct SceneBuilder {
     std::map<std::string, uint32_t> image_ids;        // by resolved file name: one mip pyramid per file
     bool any_textured = false;                        // a material / surface samples an image texture per hit
     std::map<std::string, uint32_t> materials, surfaces, mediums;
+    // materials / primitives of kinds that are not built: the scene files of the reference pull whole libraries of
+    // them in (common_materials.json, common_primitives.json), so the error is raised where one is actually USED
+    std::map<std::string, std::string> unsupported_materials, unsupported_prims;
     std::map<std::string, PrimRec> prims;
     std::vector<V3> avg_emissive;                     // per surface
     struct InstRec { spt_instance inst; Affine trans; std::string name; };
@@ -717,7 +720,9 @@ struct SceneBuilder {
                 m.c1[k] = ld / (3.5f + 100.0f * (q2 * q2));
             }
         } else if (ty == "pndf_conductor" || ty == "pndf_plastic") {
-            throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)");
+            if (materials.count(name) || unsupported_materials.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated material name '" + name + "'");
+            unsupported_materials[name] = p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)";
+            return;   // its keys are not inspected: no unused-key warnings for a material that is not built
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
         }
@@ -751,7 +756,7 @@ struct SceneBuilder {
                 any_textured = true;
             }
         }
-        if (materials.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated material name '" + name + "'");
+        if (materials.count(name) || unsupported_materials.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated material name '" + name + "'");
         materials[name] = (uint32_t)hs.materials.size();
         hs.materials.push_back(m);
         p.check_unused();
@@ -800,11 +805,13 @@ struct SceneBuilder {
             rec.type = SPT_PRIM_MESH;
             rec.id = add_mesh(m, rec.box);
         } else if (ty == "cubic_bezier" || ty == "catmull_clark") {
-            throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": primitive type '" + ty + "' is outside the hot-path scope (SURVEY 2 #4)");
+            if (prims.count(name) || unsupported_prims.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated primitive name '" + name + "'");
+            unsupported_prims[name] = p.name() + ": primitive type '" + ty + "' is outside the hot-path scope (SURVEY 2 #4)";
+            return;
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
         }
-        if (prims.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated primitive name '" + name + "'");
+        if (prims.count(name) || unsupported_prims.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated primitive name '" + name + "'");
         prims[name] = rec;
         p.check_unused();
     }
@@ -870,6 +877,7 @@ struct SceneBuilder {
         std::string name = p.get_str("name");
         p.set_name("surface-" + name);
         std::string mat = p.get_str("material");
+        if (unsupported_materials.count(mat)) throw HostError(SPT_HOST_ERR_UNSUPPORTED, unsupported_materials[mat]);
         auto mi = materials.find(mat);
         if (mi == materials.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no material named '" + mat + "'");
         uint32_t normal_map = 0, emissive_map = 0;   // texture node + 1
@@ -923,11 +931,13 @@ struct SceneBuilder {
             surf = it->second;
         } else {
             std::string mn = p.get_str("material");
+            if (unsupported_materials.count(mn)) throw HostError(SPT_HOST_ERR_UNSUPPORTED, unsupported_materials[mn]);
             auto it = materials.find(mn);
             if (it == materials.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no material named '" + mn + "'");
             surf = add_surface(it->second, {0, 0, 0}, false, -1);
         }
         std::string pn = p.get_str("primitive");
+        if (unsupported_prims.count(pn)) throw HostError(SPT_HOST_ERR_UNSUPPORTED, unsupported_prims[pn]);
         auto pi = prims.find(pn);
         if (pi == prims.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no primitive named '" + pn + "'");
         if (instances.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated instance name '" + name + "'");

@@ -72,14 +72,28 @@ def test_missing_and_mistyped_fields_fail_like_the_reference(tmp_path):
     assert e.value.status == 100
 
 
-def test_out_of_scope_features_are_reported_not_ignored(tmp_path):
-    for mutate in (lambda s: s["materials"].append({"type": "pndf_conductor", "name": "p"}),
-                   lambda s: s["primitives"].append({"type": "catmull_clark", "name": "cc", "ply_file": "x.ply"})):
-        bad = json.loads(json.dumps(BASE))
+def test_out_of_scope_features_are_reported_when_used(tmp_path):
+    """The reference's scenes pull whole libraries of materials / primitives in (common_*.json): kinds that are not
+    built only raise where an instance or surface actually uses one."""
+    lib_only = json.loads(json.dumps(BASE))
+    lib_only["materials"].append({"type": "pndf_conductor", "name": "p", "whatever": 1})
+    lib_only["primitives"].append({"type": "catmull_clark", "name": "cc", "ply_file": "x.ply"})
+    lib_only["primitives"].append({"type": "cubic_bezier", "name": "bz"})
+    assert load(tmp_path, lib_only).desc.n_instances == 1
+    for mutate in (lambda s: s["instances"].append({"name": "j", "primitive": "s", "material": "p"}),
+                   lambda s: s["instances"].append({"name": "j", "primitive": "cc", "material": "m"}),
+                   lambda s: s["instances"].append({"name": "j", "primitive": "bz", "material": "m"}),
+                   lambda s: s["surfaces"].append({"name": "sf", "material": "p"})):
+        bad = json.loads(json.dumps(lib_only))
         mutate(bad)
         with pytest.raises(spt.SptError) as e:
             load(tmp_path, bad)
-        assert e.value.status == 103
+        assert e.value.status == 103 and "outside the hot-path scope" in str(e.value)
+    dup = json.loads(json.dumps(lib_only))
+    dup["materials"].append({"type": "lambert", "name": "p", "albedo": "w"})
+    with pytest.raises(spt.SptError) as e:
+        load(tmp_path, dup)
+    assert "Duplicated material" in str(e.value)
 
 
 def test_sections_as_external_files_nested_arrays_and_comments(tmp_path):
