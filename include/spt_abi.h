@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 6
+#define SPT_ABI_VERSION 7
 
 typedef int32_t spt_status;
 enum {
@@ -37,7 +37,7 @@ enum {
     SPT_ERR_INVALID_ARG = 1,   /* null pointer, bad size, inconsistent descriptor */
     SPT_ERR_NO_DEVICE = 2,     /* no HIP device / not gfx950 / device index out of range */
     SPT_ERR_HIP = 3,           /* a HIP runtime call failed (message has the HIP error string) */
-    SPT_ERR_UNSUPPORTED = 4,   /* feature outside the hot-path scope (e.g. filter radius > 0.5) */
+    SPT_ERR_UNSUPPORTED = 4,   /* feature outside the hot-path scope (e.g. an unknown primitive type) */
     SPT_ERR_OUT_OF_MEMORY = 5
 };
 
@@ -296,8 +296,14 @@ typedef struct spt_render_params {
                                       0 = packed (strip_rows * width * 12).  shard_count * strip_rows * width * 12 with
                                       rgb_mean_out pointing at the shard's first row inside a full-image film makes every
                                       rank write its rows in place (one strided DMA, no host-side scatter) */
+    float filter_radius;           /* BoxFilter::radius (src/filter/boxf.rs:5-14); read only with SPT_RENDER_BOX_RADIUS,
+                                      otherwise 0.5 (every sample of a pixel and no other) */
+    uint32_t reserved0;
 } spt_render_params;
-enum { SPT_RENDER_PROFILE = 1u /* time each kernel class with HIP events */ };
+enum {
+    SPT_RENDER_PROFILE = 1u,       /* time each kernel class with HIP events */
+    SPT_RENDER_BOX_RADIUS = 2u     /* filter_radius is set */
+};
 
 #define SPT_N_KERNELS 7
 /* SHADE_FIRST: the shade launches of bounce 0 (one per pass, nearly all path vertices); SHADE: bounces >= 1 */
@@ -341,7 +347,8 @@ void spt_scene_destroy(spt_scene* scene);
 
 /* The hot path: RendererT::render for one image shard.  rgb_mean_out receives
  * shard_rows*width*3 f32 = per-pixel mean radiance (Film::filter_pixel with the
- * box filter of radius <= 0.5, src/core/film.rs:71-91), row 0 = top.  Synchronous. */
+ * box filter, src/core/film.rs:71-92: the sum of the samples of the (2 ceil(radius - 0.5) + 1)^2 pixels around it
+ * over the number of those samples whose offset lies within `radius`), row 0 = top.  Synchronous. */
 spt_status spt_render(const spt_scene* scene, const spt_camera* cam, const spt_render_params* params,
                       float* rgb_mean_out, spt_render_stats* stats /* may be NULL */);
 /* Number of image rows spt_render writes for these params. */

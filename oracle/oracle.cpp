@@ -29,8 +29,9 @@
 //       form (include/spt_detmath.h).
 //   D2  sin/cos/ln/exp/acos/atan2 come from include/spt_detmath.h so that the GPU can
 //       match bit-for-bit (ORACLE_LIBM switches to libm to measure the difference).
-//   D3  Film: running f32 sum per pixel instead of a Vec of samples (src/core/film.rs:47-51);
-//       identical result for the box filter of radius <= 0.5.
+//   D3  Film: for the box filter of radius 0.5 a running f32 sum per pixel instead of a Vec of
+//       samples (src/core/film.rs:47-51), identical result; any other radius keeps the samples and
+//       runs filter_pixel as written (film.rs:71-92).
 //   D4  BVH: the flattened arrays of include/spt_abi.h built by the host loader, traversed
 //       in the reference's order (push left, push right, pop; src/primitive/bvh.rs:262-283).
 //       ORACLE_SLAB_RECIPROCAL evaluates the slab test with a precomputed 1/d (what the
@@ -43,6 +44,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -1782,44 +1784,110 @@ int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_r
     const float width_inv = 1.0f / (float)p.width, height_inv = 1.0f / (float)p.height;
     const float spp_sqrt_inv = 1.0f / spt_sqrt((float)p.spp);                               // pt.rs:253-254
     const float aux_dx = aspect * width_inv * spp_sqrt_inv, aux_dy = height_inv * spp_sqrt_inv;
-    auto work = [&](int t) {
-        Ctx cx{desc, f, Math{f.libm}, &counters[(size_t)t]};
-        uint32_t per = nrows / (uint32_t)n_threads;
-        uint32_t from = (uint32_t)t * per, to = (t + 1 == n_threads) ? nrows : (uint32_t)(t + 1) * per;
-        for (uint32_t rr = from; rr < to; ++rr) {
-            uint32_t j = rows[rr];
-            for (uint32_t i = 0; i < p.width; ++i) {
-                uint32_t pixel = j * p.width + i;
-                Color sum = gray(0.0f);
-                for (uint32_t s = 0; s < p.spp; ++s) {
-                    Rng rng{spt_rng_seed(p.seed, pixel, s)};
-                    float ox, oy;
-                    pixel_offset(p, pixel, s, rng, &ox, &oy);
-                    float x = (((float)i + ox) * width_inv - 0.5f) * aspect;             // pt.rs:269
-                    float y = ((float)(p.height - j - 1) + oy) * height_inv - 0.5f;      // pt.rs:270-271
-                    Ray ray = camera_ray(*cam, x, y);
-                    {   // generate_ray_with_aux_ray (camera/mod.rs:15-21) with the offsets of pt.rs:272-275
-                        Ray rx = camera_ray(*cam, x + aux_dx, y), ry = camera_ray(*cam, x, y + aux_dy);
-                        ray.has_aux = true;
-                        ray.x_origin = rx.origin; ray.x_direction = rx.direction;
-                        ray.y_origin = ry.origin; ray.y_direction = ry.direction;
+    // one camera sample (pt.rs:266-278): its colour and the sampler offsets the film keeps with it
+    auto sample = [&](Ctx& cx, uint32_t i, uint32_t j, uint32_t s, float* ox, float* oy) -> Color {
+        uint32_t pixel = j * p.width + i;
+        Rng rng{spt_rng_seed(p.seed, pixel, s)};
+        pixel_offset(p, pixel, s, rng, ox, oy);
+        float x = (((float)i + *ox) * width_inv - 0.5f) * aspect;             // pt.rs:269
+        float y = ((float)(p.height - j - 1) + *oy) * height_inv - 0.5f;      // pt.rs:270-271
+        Ray ray = camera_ray(*cam, x, y);
+        {   // generate_ray_with_aux_ray (camera/mod.rs:15-21) with the offsets of pt.rs:272-275
+            Ray rx = camera_ray(*cam, x + aux_dx, y), ry = camera_ray(*cam, x, y + aux_dy);
+            ray.has_aux = true;
+            ray.x_origin = rx.origin; ray.x_direction = rx.direction;
+            ray.y_origin = ry.origin; ray.y_direction = ry.direction;
+        }
+        return trace_ray(cx, ray, rng, p.max_depth);
+    };
+    auto run_threads = [&](const std::function<void(int)>& work) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    };
+    // BoxFilter (boxf.rs:5-34); radius 0.5 without the flag
+    const float radius = (p.flags & SPT_RENDER_BOX_RADIUS) ? p.filter_radius : 0.5f;
+    uint64_t traced_rows = nrows;
+    if (radius == 0.5f) {
+        // D3: radius_int = 0 and every weight is 1 (offsets lie in [0, 1)), so filter_pixel is the in-order sum of the
+        // pixel's own samples over spp and the Vec of samples need not be kept
+        run_threads([&](int t) {
+            Ctx cx{desc, f, Math{f.libm}, &counters[(size_t)t]};
+            uint32_t per = nrows / (uint32_t)n_threads;
+            uint32_t from = (uint32_t)t * per, to = (t + 1 == n_threads) ? nrows : (uint32_t)(t + 1) * per;
+            for (uint32_t rr = from; rr < to; ++rr) {
+                uint32_t j = rows[rr];
+                for (uint32_t i = 0; i < p.width; ++i) {
+                    Color sum = gray(0.0f);
+                    for (uint32_t s = 0; s < p.spp; ++s) {
+                        float ox, oy;
+                        Color c = sample(cx, i, j, s, &ox, &oy);
+                        sum = sum + c;  // film.rs:87: color += sample.color
                     }
-                    Color c = trace_ray(cx, ray, rng, p.max_depth);
-                    sum = sum + c;  // film.rs:87: color += sample.color
+                    Color mean = sum / (float)p.spp;  // film.rs:91: color / weight_sum
+                    float* o = rgb_mean_out + ((size_t)rr * p.width + i) * 3;
+                    o[0] = mean.r; o[1] = mean.g; o[2] = mean.b;
                 }
-                Color mean = sum / (float)p.spp;  // film.rs:91: color / weight_sum
-                float* o = rgb_mean_out + ((size_t)rr * p.width + i) * 3;
-                o[0] = mean.r; o[1] = mean.g; o[2] = mean.b;
+            }
+        });
+    } else {
+        // The reference's Film as it is (film.rs:11-51): every sample of every pixel with (offset - 0.5) (pt.rs:278),
+        // here for the rows this shard's filter footprint reaches, then filter_pixel (film.rs:71-92) per owned pixel.
+        const int32_t R = (int32_t)std::ceil(radius - 0.5f);   // boxf.rs:12
+        struct SampleData { float ox, oy; Color color; };
+        std::vector<int64_t> row_slot(p.height, -1);
+        std::vector<uint32_t> need;
+        for (uint32_t j = 0; j < p.height; ++j) {
+            bool wanted = false;
+            for (int32_t d = -R; d <= R && !wanted; ++d) {
+                int64_t jj = (int64_t)j + d;
+                wanted = jj >= 0 && jj < (int64_t)p.height && row_in_shard(p, (uint32_t)jj);
+            }
+            if (wanted) { row_slot[j] = (int64_t)need.size(); need.push_back(j); }
+        }
+        traced_rows = need.size();
+        std::vector<SampleData> data(need.size() * (size_t)p.width * p.spp);
+        const uint32_t nneed = (uint32_t)need.size();
+        run_threads([&](int t) {
+            Ctx cx{desc, f, Math{f.libm}, &counters[(size_t)t]};
+            for (uint32_t rr = (uint32_t)t; rr < nneed; rr += (uint32_t)n_threads) {
+                uint32_t j = need[rr];
+                for (uint32_t i = 0; i < p.width; ++i)
+                    for (uint32_t s = 0; s < p.spp; ++s) {
+                        float ox, oy;
+                        Color c = sample(cx, i, j, s, &ox, &oy);
+                        data[((size_t)rr * p.width + i) * p.spp + s] = SampleData{ox - 0.5f, oy - 0.5f, c};   // film.rs:47-51
+                    }
+            }
+        });
+        for (uint32_t rr = 0; rr < nrows; ++rr) {
+            const int32_t y = (int32_t)rows[rr];
+            for (uint32_t x = 0; x < p.width; ++x) {
+                Color color = gray(0.0f);
+                float weight_sum = 0.0f;
+                for (int32_t dj = -R; dj <= R; ++dj) {
+                    if (y + dj < 0 || y + dj >= (int32_t)p.height) continue;
+                    for (int32_t di = -R; di <= R; ++di) {
+                        if ((int32_t)x + di < 0 || (int32_t)x + di >= (int32_t)p.width) continue;
+                        const SampleData* sd = &data[((size_t)row_slot[(size_t)(y + dj)] * p.width + (size_t)((int32_t)x + di)) * p.spp];
+                        for (uint32_t s = 0; s < p.spp; ++s) {
+                            float wx = (float)di + sd[s].ox, wy = (float)dj + sd[s].oy;
+                            float weight = (spt_abs(wx) <= radius && spt_abs(wy) <= radius) ? 1.0f : 0.0f;   // boxf.rs:27-33
+                            color = color + sd[s].color;   // film.rs:87: the colour is not weighted
+                            weight_sum += weight;
+                        }
+                    }
+                }
+                Color out = color / weight_sum;   // film.rs:91
+                float* o = rgb_mean_out + ((size_t)rr * p.width + x) * 3;
+                o[0] = out.r; o[1] = out.g; o[2] = out.b;
             }
         }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
+    }
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        stats->samples = (uint64_t)nrows * p.width * p.spp;
+        stats->samples = traced_rows * p.width * p.spp;
         stats->threads = (uint32_t)n_threads;
         for (auto& c : counters) {
             stats->segments_closest += c.closest; stats->segments_shadow += c.shadow;

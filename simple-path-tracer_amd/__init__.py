@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 6
+SPT_ABI_VERSION = 7
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -151,6 +151,7 @@ class Camera(C.Structure):
 
 SAMPLER_RANDOM, SAMPLER_JITTERED, SAMPLER_RECURRENCE = 0, 1, 2
 RENDER_PROFILE = 1
+RENDER_BOX_RADIUS = 2
 N_KERNELS = 7
 KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other", "shade_first")
 
@@ -160,7 +161,7 @@ class RenderParams(C.Structure):
                 ("sampler", C.c_uint32), ("division_x", C.c_uint32), ("division_y", C.c_uint32),
                 ("seed", C.c_uint64), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
                 ("strip_rows", C.c_uint32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32),
-                ("out_strip_stride", C.c_uint64)]
+                ("out_strip_stride", C.c_uint64), ("filter_radius", C.c_float), ("reserved0", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
@@ -398,16 +399,18 @@ class PathTracer:
 
     def params(self, width: int, height: int, shard_index: int = 0, shard_count: int = 1, strip_rows: int = 16,
                samples_per_pass: int = 0, flags: int = 0) -> RenderParams:
-        if self.filter_radius > 0.5:
-            # Film::filter_pixel sums unweighted colours over neighbours for radius > 0.5
-            # (reference quirk Q1, src/core/film.rs:82-90); only the box radius <= 0.5 is in scope.
-            raise SptError(4, "box filter radius > 0.5 is outside the hot-path scope")
         p = RenderParams()
         p.width, p.height, p.spp, p.max_depth = width, height, self.spp, self.max_depth
         p.sampler, p.division_x, p.division_y = self.sampler, self.division_x, self.division_y
         p.seed = self.seed
         p.shard_index, p.shard_count, p.strip_rows = shard_index, shard_count, strip_rows
         p.samples_per_pass, p.flags = samples_per_pass, flags
+        if self.filter_radius != 0.5:
+            # BoxFilter of any radius (src/filter/boxf.rs): Film::filter_pixel sums the UNWEIGHTED colours of the
+            # (2 ceil(radius - 0.5) + 1)^2 pixels around a pixel and divides by the number of those samples whose
+            # offset lies within the radius (reference quirk Q1, src/core/film.rs:82-91); 0.5 is the plain mean
+            p.flags |= RENDER_BOX_RADIUS
+            p.filter_radius = self.filter_radius
         return p
 
     def render_shard(self, scene: Scene, config: OutputConfig, device: int = 0, shard_index: int = 0,

@@ -55,10 +55,6 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "Error: %s\n", spt_host_last_error());
         return 1;
     }
-    if (radius > 0.5f) {
-        std::fprintf(stderr, "Error: box filter radius > 0.5 is outside the hot-path scope\n");
-        return 1;
-    }
     if (spp_override && params.sampler != SPT_SAMPLER_JITTERED) params.spp = spp_override;
     spt_camera cam;
     if (spt_host_scene_camera(hs, camera.empty() ? nullptr : camera.c_str(), &cam) != SPT_OK) {

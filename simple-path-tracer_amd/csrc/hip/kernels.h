@@ -59,6 +59,8 @@ struct RenderCtx {
     uint32_t width, height, spp, max_depth, sampler, division_x, division_y;
     uint64_t seed;
     uint32_t shard_index, shard_count, strip_rows;
+    uint32_t row_base;        // image row of local row 0 before the strip formula (0 for a shard; the first row of a
+                              // band when a wide box filter renders bands of whole rows, see spt_render)
     uint32_t n_pixels;        // pixels of this shard
     uint32_t rows;            // image rows of this shard (n_pixels = rows * width)
     uint32_t tiles_x;         // 16x16 tiles per row of tiles
@@ -71,6 +73,8 @@ struct RenderCtx {
     uint32_t* counts;         // [bounce][3 queues][kShards] lengths, one 128-B line each (see q_count)
     uint32_t shard_cap;       // entries per queue shard
     float* rad;               // 3 planes [c][s][pixel] of per-sample radiance
+    size_t rad_plane;         // floats per plane: pass_samples * n_pixels, or spp * n_pixels when every sample is kept
+                              // (wide box filter: rad then points at the pass's first sample inside the plane)
     float* film;              // n_pixels * 3 running sums
     uint32_t* first_slot;     // per pixel: first sample of the pass that uses a rad slot
     float aspect, width_inv, height_inv, spp_inv;
@@ -87,6 +91,11 @@ struct RenderCtx {
 };
 
 SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+// image row of a local row of this shard (row strips dealt round-robin, spt_abi.h)
+SPT_DEV uint32_t global_row(const RenderCtx& rc, uint32_t row_local) {
+    const uint32_t strip = row_local / rc.strip_rows;
+    return rc.row_base + (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
+}
 
 // Every queue is split into kShards sub-queues with their own length counter on their
 // own 128-byte line: a block only ever appends to / consumes shard (blockIdx.x % kShards).
@@ -198,8 +207,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     const uint32_t row_local = ty * kTile + (threadIdx.x / kTile);
     const bool valid = (i < rc.width) && (row_local < rc.rows);
     const uint32_t lp = valid ? row_local * rc.width + i : 0u;
-    const uint32_t strip = row_local / rc.strip_rows;
-    const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
+    const uint32_t j = global_row(rc, row_local);
     const uint32_t pixel = j * rc.width + i;
     const bool has_env = sc.env_w != 0u;
     const bool lazy_rng = rc.sampler == SPT_SAMPLER_RECURRENCE;  // the R2 sampler draws nothing: seed hits only
@@ -207,7 +215,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     f3 sum = mk3(0, 0, 0);
     if (!kChunked && valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
     uint32_t first = kChunked ? 0u : rc.pass_samples;
-    const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    const size_t plane = rc.rad_plane;
     uint32_t* hit_counter = q_count(rc.counts, 0, Q_HIT, shard);
     // A pixel whose whole footprint lies outside the projected bounds of the scene cannot hit anything with any
     // of its samples.  Without an environment all of them are black and leave no trace (film += 0, no radiance
@@ -286,7 +294,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
 }
 
 SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
-    const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    const size_t plane = rc.rad_plane;
     rc.rad[slot] = rc.rad[slot] + c.x;
     rc.rad[plane + slot] = rc.rad[plane + slot] + c.y;
     rc.rad[2 * plane + slot] = rc.rad[2 * plane + slot] + c.z;
@@ -370,8 +378,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 slot = __float_as_uint(b.w);
                 const uint32_t s_local = slot / rc.n_pixels, lp = slot - s_local * rc.n_pixels;
                 const uint32_t row_local = lp / rc.width, col = lp - row_local * rc.width;
-                const uint32_t strip = row_local / rc.strip_rows;
-                const uint32_t j = (strip * rc.shard_count + rc.shard_index) * rc.strip_rows + (row_local - strip * rc.strip_rows);
+                const uint32_t j = global_row(rc, row_local);
                 rng.s = spt_rng_seed(rc.seed, j * rc.width + col, rc.pass_first + s_local);
                 if (kTex) {
                     // the auxiliary rays of generate_ray_with_aux_ray (camera/mod.rs:15-21, offsets of pt.rs:272-275)
@@ -827,7 +834,7 @@ __global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
     if (lp >= rc.n_pixels) return;
     const uint32_t first = rc.first_slot[lp];
     if (first >= rc.pass_samples) return;
-    const size_t plane = (size_t)rc.pass_samples * rc.n_pixels;
+    const size_t plane = rc.rad_plane;
     f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
     // the additions are sequential (sample order = the reference's, film.rs:87), the loads are not: 8 samples
     // (24 loads) in flight per lane, which matters when a narrow shard leaves few pixels to hide latency with
@@ -854,6 +861,76 @@ __global__ void __launch_bounds__(256) k_finish(RenderCtx rc, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rc.n_pixels * 3u) return;
     out[i] = rc.film[i] * rc.spp_inv;
+}
+
+// ---------------------------------------------------------------------------- general box filter
+// BoxFilter::weight (src/filter/boxf.rs:27-33) of sample s of `pixel` seen from a pixel (di, dj) away: the film keeps
+// (offset - 0.5) per sample (pt.rs:278) and filter_pixel adds the pixel distance (film.rs:84-85).  The offsets are the
+// sampler's first draws of the sample's stream, so they are recomputed here instead of being stored.
+SPT_DEV float box_weight(const RenderCtx& rc, uint32_t pixel, uint32_t s, int32_t di, int32_t dj, float radius) {
+    DRng rng;
+    rng.s.state = 0ull;
+    if (rc.sampler != SPT_SAMPLER_RECURRENCE) rng.s = spt_rng_seed(rc.seed, pixel, s);
+    float ox, oy;
+    pixel_offset(rc, pixel, s, rng, &ox, &oy);
+    const float wx = (float)di + (ox - 0.5f), wy = (float)dj + (oy - 0.5f);
+    return (fabsf(wx) <= radius && fabsf(wy) <= radius) ? 1.0f : 0.0f;
+}
+
+// radius_int <= 0 (radius <= 0.5): the colour is the pixel's own in-order sum (rc.film), the weight sum counts the
+// samples whose offset lies inside the box (all of them at radius 0.5, which is k_finish).  radius_int < 0
+// (radius <= -0.5) leaves both loops of filter_pixel empty: 0 * (1 / 0).
+__global__ void __launch_bounds__(256) k_finish_box(RenderCtx rc, float* out, float radius, int32_t R) {
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= rc.n_pixels) return;
+    f3 sum = mk3(0, 0, 0);
+    float wsum = 0.0f;
+    if (R == 0) {
+        const uint32_t row_local = lp / rc.width, col = lp - row_local * rc.width;
+        const uint32_t pixel = global_row(rc, row_local) * rc.width + col;
+        sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+        for (uint32_t s = 0; s < rc.spp; ++s) wsum += box_weight(rc, pixel, s, 0, 0, radius);
+    }
+    const f3 c = sum * (1.0f / wsum);   // film.rs:91, Color / f32 = Color * (1 / f32) (color.rs:125-131)
+    out[3 * lp] = c.x; out[3 * lp + 1] = c.y; out[3 * lp + 2] = c.z;
+}
+
+// radius_int >= 1: Film::filter_pixel (film.rs:71-92) over the kept samples of a band of whole rows.  Rows j, then
+// columns i, then the samples of that pixel in the order they were added, one running colour sum (the colour is NOT
+// weighted - film.rs:87 adds sample.color as is - only weight_sum looks at the offsets).
+struct BoxJob {
+    const float* rad;               // 3 planes [c][sample][band pixel]
+    uint32_t band_base, band_rows;  // image rows held by the planes
+    uint32_t out_j0, out_rows;      // image rows to filter
+    float* out;                     // first pixel of row out_j0 in the packed output of the shard
+    int32_t R;
+    float radius;
+};
+__global__ void __launch_bounds__(256) k_filter_box(RenderCtx rc, BoxJob job) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= job.out_rows * rc.width) return;
+    const uint32_t row = idx / rc.width, x = idx - row * rc.width;
+    const int32_t y = (int32_t)(job.out_j0 + row);
+    const size_t n_band = (size_t)job.band_rows * rc.width, plane = n_band * rc.spp;
+    f3 sum = mk3(0, 0, 0);
+    float wsum = 0.0f;
+    for (int32_t dj = -job.R; dj <= job.R; ++dj) {
+        const int32_t jj = y + dj;
+        if (jj < 0 || jj >= (int32_t)rc.height) continue;
+        for (int32_t di = -job.R; di <= job.R; ++di) {
+            const int32_t ii = (int32_t)x + di;
+            if (ii < 0 || ii >= (int32_t)rc.width) continue;
+            const uint32_t pixel = (uint32_t)jj * rc.width + (uint32_t)ii;
+            const size_t lp = (size_t)((uint32_t)jj - job.band_base) * rc.width + (uint32_t)ii;
+            for (uint32_t s = 0; s < rc.spp; ++s) {
+                const size_t ri = (size_t)s * n_band + lp;
+                sum = sum + mk3(job.rad[ri], job.rad[plane + ri], job.rad[2 * plane + ri]);
+                wsum += box_weight(rc, pixel, s, di, dj, job.radius);
+            }
+        }
+    }
+    const f3 c = sum * (1.0f / wsum);
+    job.out[3 * (size_t)idx] = c.x; job.out[3 * (size_t)idx + 1] = c.y; job.out[3 * (size_t)idx + 2] = c.z;
 }
 
 // ---------------------------------------------------------------------------- test seams

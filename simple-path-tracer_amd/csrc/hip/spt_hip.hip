@@ -994,131 +994,18 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         const uint32_t shard_count = p.shard_count ? p.shard_count : 1u, strip_rows = p.strip_rows ? p.strip_rows : 1u;
         if (p.shard_index >= shard_count) fail(SPT_ERR_INVALID_ARG, "render: shard_index >= shard_count");
         if ((uint64_t)p.width * p.height > 0xffffffffull) fail(SPT_ERR_UNSUPPORTED, "render: more than 2^32 pixels");
-        const uint32_t rows = shard_row_count(p);
-        const uint64_t n_pix64 = (uint64_t)rows * p.width;
+        const uint32_t own_rows = shard_row_count(p);
+        const uint64_t own_pix64 = (uint64_t)own_rows * p.width;
         if (stats) std::memset(stats, 0, sizeof *stats);
-        if (n_pix64 == 0) return SPT_OK;
-        if (n_pix64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: shard larger than 2^31 pixels");
-        const uint32_t n_pix = (uint32_t)n_pix64;
+        if (own_pix64 == 0) return SPT_OK;
+        if (own_pix64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: shard larger than 2^31 pixels");
+        const uint32_t own_pix = (uint32_t)own_pix64;
+        // BoxFilter (src/filter/boxf.rs:11-14): radius_int = ceil(radius - 0.5) neighbour pixels each way
+        const float radius = (p.flags & SPT_RENDER_BOX_RADIUS) ? p.filter_radius : 0.5f;
+        if (!(radius == radius) || std::fabs(radius) > 64.0f) fail(SPT_ERR_UNSUPPORTED, "render: box filter radius must be finite and at most 64");
+        const int32_t R = (int32_t)std::ceil(radius - 0.5f);
         HIP_CHECK(hipSetDevice(sc->device));
-
-        // samples per pass: keep the queues around a few million entries
-        uint32_t spp_pass = p.samples_per_pass;
-        if (spp_pass == 0) {
-            const uint64_t target = 128ull << 20;
-            spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
-        }
-        spp_pass = std::min(spp_pass, p.spp);
-        // queue shards: shard s holds what the primary tiles mapped to it can emit, which also bounds
-        // every later generation of that shard
-        const uint32_t tiles_x = (p.width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
-        const uint32_t pix_blocks = tiles_x * tiles_y;
-        uint32_t max_tiles = 0;
-        {
-            std::vector<uint32_t> per(kShards, 0u);
-            for (uint32_t ty = 0; ty < tiles_y; ++ty)
-                for (uint32_t tx = 0; tx < tiles_x; ++tx) max_tiles = std::max(max_tiles, ++per[(tx + 9u * ty) % kShards]);
-        }
-        const uint64_t shard_cap64 = (uint64_t)max_tiles * kBlock * spp_pass;
-        const uint64_t cap64 = shard_cap64 * kShards;
-        if (cap64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: pass too large (lower samples_per_pass)");
-        const size_t cap = (size_t)cap64;
-        const uint64_t rad64 = (uint64_t)n_pix * spp_pass;
-
-        for (int k = 0; k < 4; ++k) { sc->qa[k].ensure(cap * 16); sc->qb[k].ensure(cap * 16); }
-        sc->qa[4].ensure(cap * 8);
-        sc->qb[4].ensure(cap * 8);
-        sc->hit_f4.ensure(cap * 16);
-        sc->hit_inst.ensure(cap * 4);
-        // see k_shade<.., kFused>.  Only the lean k_shade<0> variant gains: with the general kernel's 220+ VGPRs
-        // the two traversals run at 2 waves / SIMD and cfg4 is faster un-fused (4.30 vs 4.00 Gsamples/s, measured)
-        const bool fused = sc->fused && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
-        if (fused) {
-            sc->hit_f4_next.ensure(cap * 16);
-            sc->hit_inst_next.ensure(cap * 4);
-        }
-        for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
-        const size_t counts_words = (size_t)(p.max_depth + 1) * Q_KINDS * kShards * 32;
-        const size_t counts_bytes = counts_words * sizeof(uint32_t);
-        sc->counts.ensure(counts_bytes);
-        sc->rad.ensure((size_t)rad64 * 3 * sizeof(float));
-        sc->film.ensure((size_t)n_pix * 3 * sizeof(float));
-        sc->first_slot.ensure((size_t)n_pix * sizeof(uint32_t));
-        sc->out.ensure((size_t)n_pix * 3 * sizeof(float));
-
-        RenderCtx rc{};
-        rc.cam.eye = f3{cam->eye[0], cam->eye[1], cam->eye[2]};
-        rc.cam.forward = f3{cam->forward[0], cam->forward[1], cam->forward[2]};
-        rc.cam.up = f3{cam->up[0], cam->up[1], cam->up[2]};
-        rc.cam.right = f3{cam->right[0], cam->right[1], cam->right[2]};
-        rc.cam.half_cot = cam->half_cot_half_fov;
-        rc.width = p.width; rc.height = p.height; rc.spp = p.spp; rc.max_depth = p.max_depth;
-        rc.sampler = p.sampler; rc.division_x = p.division_x; rc.division_y = p.division_y;
-        rc.seed = p.seed;
-        rc.shard_index = p.shard_index; rc.shard_count = shard_count; rc.strip_rows = strip_rows;
-        rc.n_pixels = n_pix;
-        rc.rows = rows;
-        rc.tiles_x = tiles_x;
-        rc.qa = PathQueue{sc->qa[0].as<float4>(), sc->qa[1].as<float4>(), sc->qa[2].as<float4>(), sc->qa[3].as<float4>(), sc->qa[4].as<uint2>()};
-        rc.qb = PathQueue{sc->qb[0].as<float4>(), sc->qb[1].as<float4>(), sc->qb[2].as<float4>(), sc->qb[3].as<float4>(), sc->qb[4].as<uint2>()};
-        rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
-        rc.hits_next = HitQueue{sc->hit_f4_next.as<float4>(), sc->hit_inst_next.as<int32_t>()};
-        rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
-        rc.counts = sc->counts.as<uint32_t>();
-        rc.shard_cap = (uint32_t)shard_cap64;
-        rc.rad = sc->rad.as<float>();
-        rc.film = sc->film.as<float>();
-        rc.first_slot = sc->first_slot.as<uint32_t>();
-        rc.aspect = (float)p.width / (float)p.height;   // pt.rs:239
-        rc.width_inv = 1.0f / (float)p.width;           // pt.rs:250-251
-        rc.height_inv = 1.0f / (float)p.height;
-        rc.spp_inv = 1.0f / (float)p.spp;
-        {   // pt.rs:253-254, 272-275
-            const float spp_sqrt_inv = 1.0f / std::sqrt((float)p.spp);
-            rc.aux_dx = rc.aspect * rc.width_inv * spp_sqrt_inv;
-            rc.aux_dy = rc.height_inv * spp_sqrt_inv;
-        }
-        {
-            double oc[3], d2 = 0;
-            for (int k = 0; k < 3; ++k) { oc[k] = sc->bs_center[k] - (double)cam->eye[k]; d2 += oc[k] * oc[k]; }
-            rc.bs_oc = f3{(float)oc[0], (float)oc[1], (float)oc[2]};
-            // a little extra slack for the f32 rounding of oc and of the test itself
-            rc.bs_c = (float)((d2 - sc->bs_radius * sc->bs_radius) * (1.0 - 1e-5));
-            rc.bs_valid = sc->bs_valid ? 1u : 0u;
-            // screen-space bound: project the 8 corners of the union of the instance boxes (double precision).
-            // A point P is seen through image coordinates (u, v) = ((x / aspect + 0.5) W, (y + 0.5) H) with
-            // x = half_cot * (P - eye).right / (P - eye).forward, y likewise with up (k_primary: pt.rs:269-271).
-            rc.cull_i0 = 0; rc.cull_i1 = (int32_t)p.width - 1; rc.cull_j0 = 0; rc.cull_j1 = (int32_t)p.height - 1;
-            if (sc->bs_valid && std::getenv("SPT_NO_PIXEL_CULL") == nullptr) {
-                double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-                bool ok = true;
-                const double ext = std::max({sc->world_hi[0] - sc->world_lo[0], sc->world_hi[1] - sc->world_lo[1], sc->world_hi[2] - sc->world_lo[2], 1e-30});
-                for (int c = 0; c < 8 && ok; ++c) {
-                    double v[3], z = 0, xr = 0, yu = 0;
-                    for (int k = 0; k < 3; ++k) {
-                        const double pad = 1e-4 * ext;   // covers the (tiny) padding of the device-side boxes
-                        v[k] = (((c >> k) & 1) ? sc->world_hi[k] + pad : sc->world_lo[k] - pad) - (double)cam->eye[k];
-                        z += v[k] * (double)cam->forward[k];
-                        xr += v[k] * (double)cam->right[k];
-                        yu += v[k] * (double)cam->up[k];
-                    }
-                    if (!(z > 1e-6 * ext)) { ok = false; break; }   // a corner beside / behind the eye: no finite bound
-                    const double x = (double)cam->half_cot_half_fov * xr / z, y = (double)cam->half_cot_half_fov * yu / z;
-                    const double u = (x / ((double)p.width / (double)p.height) + 0.5) * (double)p.width, w = (y + 0.5) * (double)p.height;
-                    umin = std::min(umin, u); umax = std::max(umax, u);
-                    vmin = std::min(vmin, w); vmax = std::max(vmax, w);
-                }
-                if (ok && std::isfinite(umin) && std::isfinite(umax) && std::isfinite(vmin) && std::isfinite(vmax)) {
-                    // pixel i covers u in [i, i + 1); row j covers v in [H - 1 - j, H - j); one pixel of slack each side
-                    const double H = (double)p.height;
-                    auto clampi = [](double x, double lo, double hi) { return (int32_t)std::max(lo, std::min(hi, x)); };
-                    rc.cull_i0 = clampi(std::floor(umin) - 1.0, -1.0, (double)p.width);
-                    rc.cull_i1 = clampi(std::floor(umax) + 1.0, -1.0, (double)p.width);
-                    rc.cull_j0 = clampi(std::floor(H - 1.0 - vmax) - 1.0, -1.0, H);
-                    rc.cull_j1 = clampi(std::floor(H - 1.0 - vmin) + 2.0, -1.0, H);
-                }
-            }
-        }
+        sc->out.ensure((size_t)own_pix * 3 * sizeof(float));
 
         hipStream_t st = sc->stream;
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
@@ -1134,8 +1021,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         const bool dyn_extend = !L && std::getenv("SPT_NO_DYN_EXTEND") == nullptr;
         auto env_u32 = [](const char* name, uint32_t dflt) { const char* v = std::getenv(name); return v ? (uint32_t)std::atoi(v) : dflt; };
         const uint32_t kDynBlocks = env_u32("SPT_DYN_BLOCKS", 2048);   // persistent blocks that pull work
-        rc.dyn_refill_below = env_u32("SPT_DYN_REFILL", kRefillBelow);
-        rc.dyn_steps = env_u32("SPT_DYN_STEPS", kStepsPerCheck);
+        const uint32_t dyn_refill_below = env_u32("SPT_DYN_REFILL", kRefillBelow), dyn_steps = env_u32("SPT_DYN_STEPS", kStepsPerCheck);
         struct Span { int cls; size_t e0; };
         std::vector<Span> spans;
         size_t ev_used = 0;
@@ -1157,146 +1043,315 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             HIP_CHECK(hipEventRecord(get_event(), st));
         };
         hipEvent_t ev_total0 = get_event(), ev_total1 = get_event();
-        // tiles of this shard that intersect the screen-space bound (all of them with an environment)
-        uint32_t active_tiles = pix_blocks;
-        uint64_t live_pixels = n_pix;
-        if (sc->d.env_w == 0u) {
-            active_tiles = 0;
-            live_pixels = 0;
-            for (uint32_t r = 0; r < rows; ++r) {
-                const uint32_t strip = r / strip_rows;
-                const int32_t j = (int32_t)((strip * shard_count + p.shard_index) * strip_rows + (r - strip * strip_rows));
-                if (j >= rc.cull_j0 && j <= rc.cull_j1)
-                    live_pixels += (uint64_t)std::max(0, std::min(rc.cull_i1, (int32_t)p.width - 1) - std::max(rc.cull_i0, 0) + 1);
-            }
-            for (uint32_t ty = 0; ty < tiles_y; ++ty)
-                for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-                    const int32_t i_lo = (int32_t)(tx * kTile), i_hi = (int32_t)std::min(p.width, (tx + 1) * kTile) - 1;
-                    bool rows_in = false;
-                    for (uint32_t r = ty * kTile; r < std::min(rows, (ty + 1) * kTile) && !rows_in; ++r) {
-                        const uint32_t strip = r / strip_rows;
-                        const int32_t j = (int32_t)((strip * shard_count + p.shard_index) * strip_rows + (r - strip * strip_rows));
-                        rows_in = j >= rc.cull_j0 && j <= rc.cull_j1;
-                    }
-                    if (rows_in && i_hi >= rc.cull_i0 && i_lo <= rc.cull_i1) ++active_tiles;
-                }
-        }
         HIP_CHECK(hipEventRecord(ev_total0, st));
-        HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
         std::vector<uint32_t> h_counts;
         uint64_t seg_closest = 0, seg_shadow = 0, primary_hits = 0, path_vertices = 0, shadow_first = 0, vertices_second = 0;
-        bool chunked_any = false;
-        for (uint32_t s0 = 0; s0 < p.spp; s0 += spp_pass) {
-            rc.pass_first = s0;
-            rc.pass_samples = std::min(spp_pass, p.spp - s0);
-            begin(SPT_K_OTHER);
-            HIP_CHECK(hipMemsetAsync(rc.counts, 0, counts_bytes, st));
-            end();
-            begin(SPT_K_PRIMARY);
-            // sample chunks per tile: aim at ~6144 busy workgroups (24 per CU; 4096 .. 8192 measured within 2 %) given the tiles inside the screen bound
-            rc.n_tiles = pix_blocks;
-            rc.primary_chunks = 1;
+        uint64_t samples_traced = 0, live_samples = 0;
+        // One window of whole image rows through the wavefront pipeline.  A shard is one window (row_base 0, the
+        // strip formula of the ABI); a wide box filter renders bands of consecutive rows (w_count = w_strip = 1).
+        // collect: keep every sample's radiance (3 planes [c][sample][pixel] in sc->rad) instead of summing it into
+        // the film.  Returns the context the resolve kernels of the caller need.
+        auto trace_window = [&](uint32_t row_base, uint32_t rows, uint32_t w_index, uint32_t w_count, uint32_t w_strip, bool collect) -> RenderCtx {
+            const uint64_t n_pix64 = (uint64_t)rows * p.width;
+            if (n_pix64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: window larger than 2^31 pixels");
+            const uint32_t n_pix = (uint32_t)n_pix64;
+            // samples per pass: keep the queues around a few million entries
+            uint32_t spp_pass = p.samples_per_pass;
+            if (spp_pass == 0) {
+                const uint64_t target = 128ull << 20;
+                spp_pass = (uint32_t)std::max<uint64_t>(1, target / n_pix);
+            }
+            spp_pass = std::min(spp_pass, p.spp);
+            // queue shards: shard s holds what the primary tiles mapped to it can emit, which also bounds
+            // every later generation of that shard
+            const uint32_t tiles_x = (p.width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
+            const uint32_t pix_blocks = tiles_x * tiles_y;
+            uint32_t max_tiles = 0;
             {
-                uint32_t want = std::min<uint32_t>(64u, (6144u + active_tiles - 1u) / std::max(active_tiles, 1u));
-                if (const char* v = std::getenv("SPT_PRIMARY_CHUNKS")) want = (uint32_t)std::max(1, std::atoi(v));
-                want = std::max(1u, std::min(want, rc.pass_samples));
-                rc.chunk_samples = (rc.pass_samples + want - 1u) / want;
-                rc.primary_chunks = (rc.pass_samples + rc.chunk_samples - 1u) / rc.chunk_samples;
+                std::vector<uint32_t> per(kShards, 0u);
+                for (uint32_t ty = 0; ty < tiles_y; ++ty)
+                    for (uint32_t tx = 0; tx < tiles_x; ++tx) max_tiles = std::max(max_tiles, ++per[(tx + 9u * ty) % kShards]);
             }
-            if (rc.primary_chunks > 1u) {
-                chunked_any = true;
-                if (L) hipLaunchKernelGGL((k_primary<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
-                else hipLaunchKernelGGL((k_primary<false, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
-            } else {
-                if (L) hipLaunchKernelGGL((k_primary<true, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
-                else hipLaunchKernelGGL((k_primary<false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+            const uint64_t shard_cap64 = (uint64_t)max_tiles * kBlock * spp_pass;
+            const uint64_t cap64 = shard_cap64 * kShards;
+            if (cap64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: pass too large (lower samples_per_pass)");
+            const size_t cap = (size_t)cap64;
+            // collect: every sample of the window is kept (wide box filter), else only the samples of one pass
+            const uint64_t rad64 = (uint64_t)n_pix * (collect ? p.spp : spp_pass);
+
+            for (int k = 0; k < 4; ++k) { sc->qa[k].ensure(cap * 16); sc->qb[k].ensure(cap * 16); }
+            sc->qa[4].ensure(cap * 8);
+            sc->qb[4].ensure(cap * 8);
+            sc->hit_f4.ensure(cap * 16);
+            sc->hit_inst.ensure(cap * 4);
+            // see k_shade<.., kFused>.  Only the lean k_shade<0> variant gains: with the general kernel's 220+ VGPRs
+            // the two traversals run at 2 waves / SIMD and cfg4 is faster un-fused (4.30 vs 4.00 Gsamples/s, measured)
+            const bool fused = sc->fused && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
+            if (fused) {
+                sc->hit_f4_next.ensure(cap * 16);
+                sc->hit_inst_next.ensure(cap * 4);
             }
-            end();
-            for (uint32_t b = 0; b < p.max_depth; ++b) {
-                begin(b == 0 ? SPT_K_SHADE_FIRST : SPT_K_SHADE);
-                if (fused) {
-                    // shade + shadow + extend of this bounce in one kernel; vertices of bounce b live in
-                    // (qa, hits) for even b and in (qb, hits_next) for odd b
-                    RenderCtx rb = rc;
-                    if (b & 1u) { std::swap(rb.qa, rb.qb); std::swap(rb.hits, rb.hits_next); }
-                    if (b == 0) hipLaunchKernelGGL((k_shade<0, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
-                    else hipLaunchKernelGGL((k_shade<0, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
-                    end();
-                    continue;
+            for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
+            const size_t counts_words = (size_t)(p.max_depth + 1) * Q_KINDS * kShards * 32;
+            const size_t counts_bytes = counts_words * sizeof(uint32_t);
+            sc->counts.ensure(counts_bytes);
+            sc->rad.ensure((size_t)rad64 * 3 * sizeof(float));
+            sc->film.ensure((size_t)n_pix * 3 * sizeof(float));
+            sc->first_slot.ensure((size_t)n_pix * sizeof(uint32_t));
+
+            RenderCtx rc{};
+            rc.cam.eye = f3{cam->eye[0], cam->eye[1], cam->eye[2]};
+            rc.cam.forward = f3{cam->forward[0], cam->forward[1], cam->forward[2]};
+            rc.cam.up = f3{cam->up[0], cam->up[1], cam->up[2]};
+            rc.cam.right = f3{cam->right[0], cam->right[1], cam->right[2]};
+            rc.cam.half_cot = cam->half_cot_half_fov;
+            rc.width = p.width; rc.height = p.height; rc.spp = p.spp; rc.max_depth = p.max_depth;
+            rc.sampler = p.sampler; rc.division_x = p.division_x; rc.division_y = p.division_y;
+            rc.seed = p.seed;
+            rc.shard_index = w_index; rc.shard_count = w_count; rc.strip_rows = w_strip;
+            rc.row_base = row_base;
+            rc.n_pixels = n_pix;
+            rc.rows = rows;
+            rc.tiles_x = tiles_x;
+            rc.qa = PathQueue{sc->qa[0].as<float4>(), sc->qa[1].as<float4>(), sc->qa[2].as<float4>(), sc->qa[3].as<float4>(), sc->qa[4].as<uint2>()};
+            rc.qb = PathQueue{sc->qb[0].as<float4>(), sc->qb[1].as<float4>(), sc->qb[2].as<float4>(), sc->qb[3].as<float4>(), sc->qb[4].as<uint2>()};
+            rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
+            rc.hits_next = HitQueue{sc->hit_f4_next.as<float4>(), sc->hit_inst_next.as<int32_t>()};
+            rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
+            rc.counts = sc->counts.as<uint32_t>();
+            rc.shard_cap = (uint32_t)shard_cap64;
+            rc.rad = sc->rad.as<float>();
+            rc.film = sc->film.as<float>();
+            rc.first_slot = sc->first_slot.as<uint32_t>();
+            rc.aspect = (float)p.width / (float)p.height;   // pt.rs:239
+            rc.width_inv = 1.0f / (float)p.width;           // pt.rs:250-251
+            rc.height_inv = 1.0f / (float)p.height;
+            rc.spp_inv = 1.0f / (float)p.spp;
+            {   // pt.rs:253-254, 272-275
+                const float spp_sqrt_inv = 1.0f / std::sqrt((float)p.spp);
+                rc.aux_dx = rc.aspect * rc.width_inv * spp_sqrt_inv;
+                rc.aux_dy = rc.height_inv * spp_sqrt_inv;
+            }
+            {
+                double oc[3], d2 = 0;
+                for (int k = 0; k < 3; ++k) { oc[k] = sc->bs_center[k] - (double)cam->eye[k]; d2 += oc[k] * oc[k]; }
+                rc.bs_oc = f3{(float)oc[0], (float)oc[1], (float)oc[2]};
+                // a little extra slack for the f32 rounding of oc and of the test itself
+                rc.bs_c = (float)((d2 - sc->bs_radius * sc->bs_radius) * (1.0 - 1e-5));
+                rc.bs_valid = sc->bs_valid ? 1u : 0u;
+                // screen-space bound: project the 8 corners of the union of the instance boxes (double precision).
+                // A point P is seen through image coordinates (u, v) = ((x / aspect + 0.5) W, (y + 0.5) H) with
+                // x = half_cot * (P - eye).right / (P - eye).forward, y likewise with up (k_primary: pt.rs:269-271).
+                rc.cull_i0 = 0; rc.cull_i1 = (int32_t)p.width - 1; rc.cull_j0 = 0; rc.cull_j1 = (int32_t)p.height - 1;
+                if (sc->bs_valid && std::getenv("SPT_NO_PIXEL_CULL") == nullptr) {
+                    double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+                    bool ok = true;
+                    const double ext = std::max({sc->world_hi[0] - sc->world_lo[0], sc->world_hi[1] - sc->world_lo[1], sc->world_hi[2] - sc->world_lo[2], 1e-30});
+                    for (int c = 0; c < 8 && ok; ++c) {
+                        double v[3], z = 0, xr = 0, yu = 0;
+                        for (int k = 0; k < 3; ++k) {
+                            const double pad = 1e-4 * ext;   // covers the (tiny) padding of the device-side boxes
+                            v[k] = (((c >> k) & 1) ? sc->world_hi[k] + pad : sc->world_lo[k] - pad) - (double)cam->eye[k];
+                            z += v[k] * (double)cam->forward[k];
+                            xr += v[k] * (double)cam->right[k];
+                            yu += v[k] * (double)cam->up[k];
+                        }
+                        if (!(z > 1e-6 * ext)) { ok = false; break; }   // a corner beside / behind the eye: no finite bound
+                        const double x = (double)cam->half_cot_half_fov * xr / z, y = (double)cam->half_cot_half_fov * yu / z;
+                        const double u = (x / ((double)p.width / (double)p.height) + 0.5) * (double)p.width, w = (y + 0.5) * (double)p.height;
+                        umin = std::min(umin, u); umax = std::max(umax, u);
+                        vmin = std::min(vmin, w); vmax = std::max(vmax, w);
+                    }
+                    if (ok && std::isfinite(umin) && std::isfinite(umax) && std::isfinite(vmin) && std::isfinite(vmax)) {
+                        // pixel i covers u in [i, i + 1); row j covers v in [H - 1 - j, H - j); one pixel of slack each side
+                        const double H = (double)p.height;
+                        auto clampi = [](double x, double lo, double hi) { return (int32_t)std::max(lo, std::min(hi, x)); };
+                        rc.cull_i0 = clampi(std::floor(umin) - 1.0, -1.0, (double)p.width);
+                        rc.cull_i1 = clampi(std::floor(umax) + 1.0, -1.0, (double)p.width);
+                        rc.cull_j0 = clampi(std::floor(H - 1.0 - vmax) - 1.0, -1.0, H);
+                        rc.cull_j1 = clampi(std::floor(H - 1.0 - vmin) + 2.0, -1.0, H);
+                    }
                 }
-                const bool tab = sc->lds_tables && std::getenv("SPT_NO_LDS_TABLES") == nullptr;   // shading tables from LDS (tab_ld)
-                const size_t shade_lds = sc->subsurface ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3>: traversal stack
-#define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
-    if (tab) {                                                                                                                                 \
-        if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
-        else hipLaunchKernelGGL((k_shade<FEAT, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);              \
-    } else {                                                                                                                                   \
-        if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);               \
-        else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);                     \
-    }
-                if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) } else { SPT_LAUNCH_SHADE(3) }
-#undef SPT_LAUNCH_SHADE
+            }
+
+            rc.dyn_refill_below = dyn_refill_below;
+            rc.dyn_steps = dyn_steps;
+            // tiles of this shard that intersect the screen-space bound (all of them with an environment)
+            uint32_t active_tiles = pix_blocks;
+            uint64_t live_pixels = n_pix;
+            if (sc->d.env_w == 0u) {
+                active_tiles = 0;
+                live_pixels = 0;
+                for (uint32_t r = 0; r < rows; ++r) {
+                    const uint32_t strip = r / w_strip;
+                    const int32_t j = (int32_t)(row_base + (strip * w_count + w_index) * w_strip + (r - strip * w_strip));
+                    if (j >= rc.cull_j0 && j <= rc.cull_j1)
+                        live_pixels += (uint64_t)std::max(0, std::min(rc.cull_i1, (int32_t)p.width - 1) - std::max(rc.cull_i0, 0) + 1);
+                }
+                for (uint32_t ty = 0; ty < tiles_y; ++ty)
+                    for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+                        const int32_t i_lo = (int32_t)(tx * kTile), i_hi = (int32_t)std::min(p.width, (tx + 1) * kTile) - 1;
+                        bool rows_in = false;
+                        for (uint32_t r = ty * kTile; r < std::min(rows, (ty + 1) * kTile) && !rows_in; ++r) {
+                            const uint32_t strip = r / w_strip;
+                            const int32_t j = (int32_t)(row_base + (strip * w_count + w_index) * w_strip + (r - strip * w_strip));
+                            rows_in = j >= rc.cull_j0 && j <= rc.cull_j1;
+                        }
+                        if (rows_in && i_hi >= rc.cull_i0 && i_lo <= rc.cull_i1) ++active_tiles;
+                    }
+            }
+            HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
+            if (collect) HIP_CHECK(hipMemsetAsync(sc->rad.p, 0, (size_t)rad64 * 3 * sizeof(float), st));   // pixels outside the screen bound write no slots
+            bool chunked_any = false;
+            for (uint32_t s0 = 0; s0 < p.spp; s0 += spp_pass) {
+                rc.pass_first = s0;
+                rc.pass_samples = std::min(spp_pass, p.spp - s0);
+                rc.rad_plane = collect ? (size_t)p.spp * n_pix : (size_t)rc.pass_samples * n_pix;
+                rc.rad = sc->rad.as<float>() + (collect ? (size_t)s0 * n_pix : 0);
+                begin(SPT_K_OTHER);
+                HIP_CHECK(hipMemsetAsync(rc.counts, 0, counts_bytes, st));
                 end();
-                // k_shadow(b) and k_extend(b) are independent unless the scene has an environment (then a missing
-                // extension ray adds its term to the same radiance slot the shadow ray of that vertex adds to, and
-                // the reference's order of the two additions has to be kept): without one, the shadow kernel runs on
-                // a side stream next to the extension kernel and is joined before the next stage reads the slots.
-                const bool side = overlap && b + 1 < p.max_depth;
-                hipStream_t ss = side ? sc->stream2 : st;
-                if (side) {
-                    HIP_CHECK(hipEventRecord(sc->ev_fork, st));
-                    HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
+                begin(SPT_K_PRIMARY);
+                // sample chunks per tile: aim at ~6144 busy workgroups (24 per CU; 4096 .. 8192 measured within 2 %) given the tiles inside the screen bound
+                rc.n_tiles = pix_blocks;
+                rc.primary_chunks = 1;
+                {
+                    uint32_t want = std::min<uint32_t>(64u, (6144u + active_tiles - 1u) / std::max(active_tiles, 1u));
+                    if (const char* v = std::getenv("SPT_PRIMARY_CHUNKS")) want = (uint32_t)std::max(1, std::atoi(v));
+                    want = std::max(1u, std::min(want, rc.pass_samples));
+                    rc.chunk_samples = (rc.pass_samples + want - 1u) / want;
+                    rc.primary_chunks = (rc.pass_samples + rc.chunk_samples - 1u) / rc.chunk_samples;
                 }
-                begin(SPT_K_SHADOW);
-                if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                if (rc.primary_chunks > 1u || collect) {   // collect: every sample owns a slot, which is what the chunked kernel does
+                    chunked_any = true;
+                    if (L) hipLaunchKernelGGL((k_primary<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    else hipLaunchKernelGGL((k_primary<false, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                } else {
+                    if (L) hipLaunchKernelGGL((k_primary<true, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    else hipLaunchKernelGGL((k_primary<false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                }
                 end();
-                if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
-                if (b + 1 < p.max_depth) {
-                    begin(SPT_K_EXTEND);
-                    if (L) hipLaunchKernelGGL(k_extend<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                    else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                    else hipLaunchKernelGGL(k_extend<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                    end();
-                }
-                if (side) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_join, 0));
-            }
-            begin(SPT_K_RESOLVE);
-            hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
-            end();
-            if (stats) {
-                h_counts.resize(counts_words);
-                HIP_CHECK(hipMemcpyAsync(h_counts.data(), rc.counts, counts_bytes, hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-                seg_closest += (uint64_t)n_pix * rc.pass_samples;
-                auto qsum = [&](uint32_t b, uint32_t q) {
-                    uint64_t t = 0;
-                    for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * Q_KINDS + q) * kShards + s) * 32];
-                    return t;
-                };
-                primary_hits += qsum(0, Q_HIT);
-                shadow_first += qsum(0, Q_SHADOW);
-                if (p.max_depth > 1) vertices_second += qsum(1, Q_HIT);
                 for (uint32_t b = 0; b < p.max_depth; ++b) {
-                    path_vertices += qsum(b, Q_HIT);
-                    seg_shadow += qsum(b, Q_SHADOW);
-                    if (b + 1 < p.max_depth) seg_closest += qsum(b, Q_EXT);
+                    begin(b == 0 ? SPT_K_SHADE_FIRST : SPT_K_SHADE);
+                    if (fused) {
+                        // shade + shadow + extend of this bounce in one kernel; vertices of bounce b live in
+                        // (qa, hits) for even b and in (qb, hits_next) for odd b
+                        RenderCtx rb = rc;
+                        if (b & 1u) { std::swap(rb.qa, rb.qb); std::swap(rb.hits, rb.hits_next); }
+                        if (b == 0) hipLaunchKernelGGL((k_shade<0, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                        else hipLaunchKernelGGL((k_shade<0, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                        end();
+                        continue;
+                    }
+                    const bool tab = sc->lds_tables && std::getenv("SPT_NO_LDS_TABLES") == nullptr;   // shading tables from LDS (tab_ld)
+                    const size_t shade_lds = sc->subsurface ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3>: traversal stack
+#define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
+        if (tab) {                                                                                                                                 \
+            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
+            else hipLaunchKernelGGL((k_shade<FEAT, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);              \
+        } else {                                                                                                                                   \
+            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);               \
+            else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);                     \
+        }
+                    if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) } else { SPT_LAUNCH_SHADE(3) }
+#undef SPT_LAUNCH_SHADE
+                    end();
+                    // k_shadow(b) and k_extend(b) are independent unless the scene has an environment (then a missing
+                    // extension ray adds its term to the same radiance slot the shadow ray of that vertex adds to, and
+                    // the reference's order of the two additions has to be kept): without one, the shadow kernel runs on
+                    // a side stream next to the extension kernel and is joined before the next stage reads the slots.
+                    const bool side = overlap && b + 1 < p.max_depth;
+                    hipStream_t ss = side ? sc->stream2 : st;
+                    if (side) {
+                        HIP_CHECK(hipEventRecord(sc->ev_fork, st));
+                        HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
+                    }
+                    begin(SPT_K_SHADOW);
+                    if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    end();
+                    if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
+                    if (b + 1 < p.max_depth) {
+                        begin(SPT_K_EXTEND);
+                        if (L) hipLaunchKernelGGL(k_extend<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else hipLaunchKernelGGL(k_extend<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        end();
+                    }
+                    if (side) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_join, 0));
                 }
+                if (!collect) {
+                    begin(SPT_K_RESOLVE);
+                    hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
+                    end();
+                }
+                if (stats) {
+                    h_counts.resize(counts_words);
+                    HIP_CHECK(hipMemcpyAsync(h_counts.data(), rc.counts, counts_bytes, hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    seg_closest += (uint64_t)n_pix * rc.pass_samples;
+                    auto qsum = [&](uint32_t b, uint32_t q) {
+                        uint64_t t = 0;
+                        for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * Q_KINDS + q) * kShards + s) * 32];
+                        return t;
+                    };
+                    primary_hits += qsum(0, Q_HIT);
+                    shadow_first += qsum(0, Q_SHADOW);
+                    if (p.max_depth > 1) vertices_second += qsum(1, Q_HIT);
+                    for (uint32_t b = 0; b < p.max_depth; ++b) {
+                        path_vertices += qsum(b, Q_HIT);
+                        seg_shadow += qsum(b, Q_SHADOW);
+                        if (b + 1 < p.max_depth) seg_closest += qsum(b, Q_EXT);
+                    }
+                }
+            }
+            samples_traced += (uint64_t)n_pix * p.spp;
+            if (chunked_any) live_samples += live_pixels * p.spp;
+            return rc;
+        };
+        if (R <= 0) {
+            const RenderCtx rc = trace_window(0, own_rows, p.shard_index, shard_count, strip_rows, false);
+            begin(SPT_K_RESOLVE);
+            const dim3 grid((own_pix + kBlock - 1) / kBlock);
+            if (radius == 0.5f) hipLaunchKernelGGL(k_finish, dim3((own_pix * 3 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, sc->out.as<float>());
+            else hipLaunchKernelGGL(k_finish_box, grid, dim3(kBlock), 0, st, rc, sc->out.as<float>(), radius, R);
+            end();
+        } else {
+            // Film::filter_pixel (film.rs:71-92) reads the samples of (2R+1)^2 pixels: each run of consecutive rows of
+            // this shard is rendered as bands of whole rows with R rows of halo, all samples kept, then filtered.
+            // The halo rows are traced again by the neighbouring band / rank: samples are a pure function of
+            // (seed, pixel, sample), so every copy of a row is the same bits.
+            std::vector<uint32_t> own;
+            for (uint32_t j = 0; j < p.height; ++j)
+                if ((j / strip_rows) % shard_count == p.shard_index) own.push_back(j);
+            uint64_t budget = 8ull << 30;   // bytes of kept radiance per band
+            if (const char* v = std::getenv("SPT_BOX_BAND_BYTES")) budget = std::max<uint64_t>(1, std::strtoull(v, nullptr, 10));
+            const uint64_t per_row = (uint64_t)p.width * p.spp * 3 * sizeof(float);
+            const uint64_t fit = std::max<uint64_t>(1, budget / per_row);
+            const uint32_t run_max = (uint32_t)std::min<uint64_t>(p.height, fit > 2ull * (uint64_t)R ? fit - 2ull * (uint64_t)R : 1ull);
+            for (size_t k = 0; k < own.size();) {
+                size_t e = k + 1;
+                while (e < own.size() && own[e] == own[e - 1] + 1u && e - k < run_max) ++e;
+                const uint32_t j0 = own[k], j1 = own[e - 1] + 1u;
+                const uint32_t b0 = j0 >= (uint32_t)R ? j0 - (uint32_t)R : 0u, b1 = (uint32_t)std::min<uint64_t>(p.height, (uint64_t)j1 + (uint64_t)R);
+                const RenderCtx rc = trace_window(b0, b1 - b0, 0u, 1u, 1u, true);
+                begin(SPT_K_RESOLVE);
+                BoxJob job{sc->rad.as<float>(), b0, b1 - b0, j0, j1 - j0, sc->out.as<float>() + k * (size_t)p.width * 3, R, radius};
+                hipLaunchKernelGGL(k_filter_box, dim3(((j1 - j0) * p.width + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, job);
+                end();
+                k = e;
             }
         }
-        begin(SPT_K_RESOLVE);
-        hipLaunchKernelGGL(k_finish, dim3((n_pix * 3 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, sc->out.as<float>());
-        end();
         HIP_CHECK(hipGetLastError());
         {
             const size_t strip_bytes = (size_t)strip_rows * p.width * 3 * sizeof(float);
             if (p.out_strip_stride == 0 || p.out_strip_stride == strip_bytes) {
-                HIP_CHECK(hipMemcpyAsync(rgb_mean_out, sc->out.p, (size_t)n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipMemcpyAsync(rgb_mean_out, sc->out.p, (size_t)own_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
             } else {
                 // strided copy-out: the shard's strips land strip by strip in a larger (full-image) film
                 if (p.out_strip_stride < strip_bytes) fail(SPT_ERR_INVALID_ARG, "render: out_strip_stride smaller than a strip");
-                const size_t full = rows / strip_rows, rest_rows = rows - full * strip_rows;
+                const size_t full = own_rows / strip_rows, rest_rows = own_rows - full * strip_rows;
                 if (full)
                     HIP_CHECK(hipMemcpy2DAsync(rgb_mean_out, p.out_strip_stride, sc->out.p, strip_bytes, strip_bytes, full, hipMemcpyDeviceToHost, st));
                 if (rest_rows)
@@ -1307,14 +1362,14 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         HIP_CHECK(hipEventRecord(ev_total1, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (stats) {
-            stats->samples = (uint64_t)n_pix * p.spp;
+            stats->samples = samples_traced;
             stats->segments_closest = seg_closest;
             stats->segments_shadow = seg_shadow;
             stats->primary_hits = primary_hits;
             stats->path_vertices = path_vertices;
             stats->shadow_first = shadow_first;
             stats->vertices_second = vertices_second;
-            stats->live_samples = chunked_any ? live_pixels * p.spp : 0;
+            stats->live_samples = live_samples;
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_total0, ev_total1));
             stats->gpu_ms = ms;

@@ -113,6 +113,9 @@ spt_status spt_host_load_renderer(const char* path, spt_render_params* params, f
         params->spp = spp;
         params->division_x = dx;
         params->division_y = dy;
+        // BoxFilter::new (src/filter/boxf.rs:11-14): any radius; 0.5 is the plain per-pixel mean
+        params->filter_radius = radius;
+        if (radius != 0.5f) params->flags |= SPT_RENDER_BOX_RADIUS;
         if (filter_radius) *filter_radius = radius;
         return SPT_OK;
     } catch (const HostError& e) {

@@ -11,16 +11,17 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _util
 
-CASES = [  # name, scene, camera, sampler, spp, (w, h), seed
-    ("film_cfg1_sphere", "cfg1_sphere.json", None, "recurrence", 16, (64, 64), 1),
-    ("film_cfg2_cube", "cfg2_cube.json", None, "recurrence", 16, (64, 64), 1),
-    ("film_t_materials", "t_materials.json", "main", "random", 16, (64, 48), 1),
-    ("film_t_power_is", "t_power_is.json", "top", "jittered", 16, (64, 48), 1),
-    ("film_t_medium", "t_medium.json", None, "random", 16, (64, 48), 1),
-    ("film_t_plastic", "t_plastic.json", None, "random", 16, (64, 48), 1),
-    ("film_t_textured", "t_textured.json", None, "recurrence", 16, (64, 48), 1),
-    ("film_t_gltf", "t_gltf.gltf", "cam", "random", 16, (64, 48), 1),
-    ("film_t_subsurface", "t_subsurface.json", None, "random", 16, (64, 48), 1),
+CASES = [  # name, scene, camera, sampler, spp, (w, h), seed, box filter radius
+    ("film_cfg1_sphere", "cfg1_sphere.json", None, "recurrence", 16, (64, 64), 1, 0.5),
+    ("film_cfg2_cube", "cfg2_cube.json", None, "recurrence", 16, (64, 64), 1, 0.5),
+    ("film_t_materials", "t_materials.json", "main", "random", 16, (64, 48), 1, 0.5),
+    ("film_t_power_is", "t_power_is.json", "top", "jittered", 16, (64, 48), 1, 0.5),
+    ("film_t_medium", "t_medium.json", None, "random", 16, (64, 48), 1, 0.5),
+    ("film_t_plastic", "t_plastic.json", None, "random", 16, (64, 48), 1, 0.5),
+    ("film_t_textured", "t_textured.json", None, "recurrence", 16, (64, 48), 1, 0.5),
+    ("film_t_gltf", "t_gltf.gltf", "cam", "random", 16, (64, 48), 1, 0.5),
+    ("film_t_subsurface", "t_subsurface.json", None, "random", 16, (64, 48), 1, 0.5),
+    ("film_cfg2_cube_box1p2", "cfg2_cube.json", None, "random", 8, (64, 64), 1, 1.2),   # film.rs:71-92 with radius_int = 1
 ]
 
 
@@ -29,9 +30,9 @@ def main():
     spt = _util.load_pkg()
     kinds = {"random": spt.SAMPLER_RANDOM, "recurrence": spt.SAMPLER_RECURRENCE, "jittered": spt.SAMPLER_JITTERED}
     os.makedirs(_util.GOLDEN, exist_ok=True)
-    for name, scene, cam, sampler, spp, (w, h), seed in CASES:
+    for name, scene, cam, sampler, spp, (w, h), seed, radius in CASES:
         sc = spt.load_scene(os.path.join(_util.SCENES, scene))
-        r = spt.PathTracer(max_depth=8, sampler=kinds[sampler], spp=spp, division_x=4, division_y=4, seed=seed)
+        r = spt.PathTracer(max_depth=8, sampler=kinds[sampler], spp=spp, division_x=4, division_y=4, seed=seed, filter_radius=radius)
         film, st = _util.oracle_render(sc, r, w, h, camera=cam, flags=0)
         rays = _util.random_rays(sc, 4096, seed=17)
         hits = _util.oracle_trace_closest(sc, rays, 0)

@@ -19,10 +19,10 @@ def _load(name):
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_oracle_reproduces_golden(case):
-    name, scene, cam, sampler, spp, (w, h), seed = case
+    name, scene, cam, sampler, spp, (w, h), seed, radius = case
     g = _load(name)
     sc = spt.load_scene(os.path.join(_util.SCENES, scene))
-    r = spt.PathTracer(max_depth=8, sampler=KINDS[sampler], spp=spp, division_x=4, division_y=4, seed=seed)
+    r = spt.PathTracer(max_depth=8, sampler=KINDS[sampler], spp=spp, division_x=4, division_y=4, seed=seed, filter_radius=radius)
     film, st = _util.oracle_render(sc, r, w, h, camera=cam)
     assert np.array_equal(film.view(np.uint32), g["film"].view(np.uint32))
     assert [st.segments_closest, st.segments_shadow, st.node_tests, st.tri_tests] == g["counters"].tolist()
@@ -34,10 +34,10 @@ def test_oracle_reproduces_golden(case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_hip_reproduces_golden(case):
-    name, scene, cam, sampler, spp, (w, h), seed = case
+    name, scene, cam, sampler, spp, (w, h), seed, radius = case
     g = _load(name)
     sc = spt.load_scene(os.path.join(_util.SCENES, scene))
-    r = spt.PathTracer(max_depth=8, sampler=KINDS[sampler], spp=spp, division_x=4, division_y=4, seed=seed)
+    r = spt.PathTracer(max_depth=8, sampler=KINDS[sampler], spp=spp, division_x=4, division_y=4, seed=seed, filter_radius=radius)
     film = r.render_shard(sc, spt.OutputConfig(w, h, None, cam))
     # golden films come from the reference-faithful slab test (six divisions per node); the kernels
     # multiply by 1/d, which can flip a cull decision in the last bit: tolerance, not bit equality

@@ -265,6 +265,53 @@ def test_many_instances_device_tlas(spt, tmp_path):
     assert np.array_equal(film.view(np.uint32)[~nan], ref_film.view(np.uint32)[~nan])
 
 
+def _same_film(got, ref):
+    nan = np.isnan(ref)
+    assert np.array_equal(nan, np.isnan(got))
+    inf = np.isinf(ref)
+    assert np.array_equal(ref[inf], got[inf])
+    ok = ~nan
+    assert np.array_equal(got[ok].view(np.uint32), ref[ok].view(np.uint32)), int((got.view(np.uint32) != ref.view(np.uint32))[ok].sum())
+
+
+@pytest.mark.parametrize("scene_name,camera,sampler,radius", [
+    ("cfg2_cube.json", None, "recurrence", 1.5),     # fused LDS pipeline, R = 1, every neighbour sample inside the box
+    ("cfg2_cube.json", None, "random", 0.8),         # R = 1, the weight sum depends on the offsets
+    ("cfg2_cube.json", None, "random", 0.3),         # R = 0: own samples only, counted when inside (empty boxes divide by 0)
+    ("cfg2_cube.json", None, "jittered", 2.2),       # R = 2
+    ("t_materials.json", "main", "random", 1.0),     # environment: every pixel is live; general shade kernel
+    ("t_textured.json", None, "random", 1.2),        # textured shade kernel (its bounce 0 redoes the sampler draw)
+])
+def test_box_filter_of_any_radius_matches_oracle(spt, scene_name, camera, sampler, radius, monkeypatch):
+    # film.rs:71-92 / boxf.rs: unweighted colours of (2R+1)^2 pixels over the count of in-radius samples
+    sc = _scene(spt, scene_name)
+    kinds = {"random": spt.SAMPLER_RANDOM, "recurrence": spt.SAMPLER_RECURRENCE, "jittered": spt.SAMPLER_JITTERED}
+    r = spt.PathTracer(max_depth=6, sampler=kinds[sampler], spp=6, division_x=3, division_y=2, seed=13, filter_radius=radius)
+    w, h = 112, 84
+    ref, _ = _util.oracle_render(sc, r, w, h, camera=camera, flags=_util.device_oracle_flags())
+    assert np.nanmax(ref[np.isfinite(ref)]) > 0.05
+    got = r.render_shard(sc, spt.OutputConfig(w, h, None, camera), samples_per_pass=4)   # 6 = 4 + 2 samples per pass
+    _same_film(got, ref)
+    # bands of a few rows (each with its halo) instead of one band: same film
+    monkeypatch.setenv("SPT_BOX_BAND_BYTES", str(w * 6 * 12 * 9))
+    _same_film(r.render_shard(sc, spt.OutputConfig(w, h, None, camera)), ref)
+    monkeypatch.delenv("SPT_BOX_BAND_BYTES")
+    # shards: each rank traces the halo rows of its strips itself
+    if radius > 0.5:
+        out = np.zeros_like(ref)
+        for k in range(3):
+            rows = spt.shard_rows(h, k, 3, 8)
+            out[rows] = r.render_shard(sc, spt.OutputConfig(w, h, None, camera), shard_index=k, shard_count=3, strip_rows=8)
+            assert r.last_stats.samples > len(rows) * w * 6
+        _same_film(out, ref)
+
+
+def test_box_filter_negative_radius_is_the_reference_nan_film(spt):
+    sc = _scene(spt, "cfg2_cube.json")
+    r = spt.PathTracer(max_depth=2, spp=2, seed=1, filter_radius=-0.75)
+    assert np.isnan(r.render_shard(sc, spt.OutputConfig(32, 16))).all()
+
+
 def test_render_error_paths(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=4)

@@ -202,9 +202,8 @@ def test_renderer_json(tmp_path):
         with pytest.raises(spt.SptError) as e:
             spt.load_renderer(str(p))
         assert msg in str(e.value)
-    wide = spt.PathTracer(filter_radius=1.5)
-    with pytest.raises(spt.SptError):
-        wide.params(8, 8)
+    wide = spt.PathTracer(filter_radius=1.5).params(8, 8)      # any box radius is carried to the device (tests/test_box_filter.py)
+    assert wide.flags & spt.RENDER_BOX_RADIUS and wide.filter_radius == 1.5
 
 
 def test_exr_roundtrip_and_png_and_u8_truncation(tmp_path):
