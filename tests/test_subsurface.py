@@ -77,7 +77,7 @@ def test_loader_builds_the_substrate(tmp_path):
             m.pop("ld")
     for t in bad["textures"]:
         if "image_file" in t:
-            t["image_file"] = os.path.join("..", os.path.relpath(os.path.join(_util.SCENES, t["image_file"]), str(tmp_path)))
+            t["image_file"] = os.path.relpath(os.path.join(_util.SCENES, t["image_file"]), str(tmp_path))
     p = tmp_path / "bad.json"
     p.write_text(json.dumps(bad))
     with pytest.raises(spt.SptError) as e:
