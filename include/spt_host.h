@@ -47,6 +47,10 @@ spt_status spt_host_load_renderer(const char* renderer_json_path, spt_render_par
 /* u8 = (clamp(c*255, 0, 255)) as u8 — truncation, no gamma (src/core/film.rs:94-99). */
 void spt_host_film_to_rgb8(const float* rgb_mean, uint64_t n_pixels, uint8_t* rgb8_out);
 spt_status spt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+/* baseline JPEG, 4:4:4, IJG quality scale (the image crate's JpegEncoder default is 75) */
+spt_status spt_host_write_jpeg(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height, int32_t quality);
+/* `image.save(path)` (src/renderer/pt.rs:292-294): the extension picks the format - png, jpg / jpeg */
+spt_status spt_host_write_image(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
 /* Minimal OpenEXR scanline I/O (RGB f32 / f16, NO_COMPRESSION / ZIPS / ZIP) for
  * `environment {type: "exr"}` (get_exr_image, src/core/loader.rs:374-390). */
@@ -55,6 +59,8 @@ spt_status spt_host_write_exr(const char* path, const float* rgb, uint32_t width
 /* PNG -> RGBA8 texels (r | g<<8 | b<<16 | a<<24) the way `image::open` + `get_pixel` present an
  * `image_file` texture (get_image, src/core/loader.rs:366-371); free with spt_host_free. */
 spt_status spt_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out);
+/* the same for a PNG or a JPEG file (told apart by content; baseline / progressive Huffman, IJG arithmetic) */
+spt_status spt_host_read_image(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out);
 void spt_host_free(void* p);
 
 const char* spt_host_last_error(void);

@@ -204,6 +204,8 @@ def host_lib() -> C.CDLL:
         lib.spt_host_film_to_rgb8.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         lib.spt_host_film_to_rgb8.restype = None
         lib.spt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.spt_host_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.spt_host_write_jpeg.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32]
         lib.spt_host_read_exr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                           C.POINTER(C.POINTER(C.c_float))]
         lib.spt_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -449,7 +451,7 @@ class PathTracer:
         when config.output_filename is set and returns the float film (H, W, 3)."""
         film = self.render_shard(scene, config, device)
         if config.output_filename:
-            write_png(config.output_filename, film)
+            write_image(config.output_filename, film)
         return film
 
 
@@ -490,8 +492,21 @@ def write_png(path: str, film: np.ndarray) -> None:
     _check_host(host_lib().spt_host_write_png(os.fspath(path).encode(), rgb8.ctypes.data, w, h))
 
 
+def write_image(path: str, film: np.ndarray) -> None:
+    """`image.save(path)` (src/renderer/pt.rs:292-294): png or jpg / jpeg by extension."""
+    rgb8 = film_to_rgb8(film)
+    h, w = rgb8.shape[:2]
+    _check_host(host_lib().spt_host_write_image(os.fspath(path).encode(), rgb8.ctypes.data, w, h))
+
+
+def write_jpeg(path: str, rgb8: np.ndarray, quality: int = 75) -> None:
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w = rgb8.shape[:2]
+    _check_host(host_lib().spt_host_write_jpeg(os.fspath(path).encode(), rgb8.ctypes.data, w, h, quality))
+
+
 def read_png(path: str) -> np.ndarray:
-    """(h, w, 4) uint8 RGBA as `image::open` + `get_pixel` present an image texture file."""
+    """(h, w, 4) uint8 RGBA as `image::open` + `get_pixel` present an image texture file (PNG or JPEG)."""
     w, h = C.c_uint32(), C.c_uint32()
     ptr = C.POINTER(C.c_uint32)()
     _check_host(host_lib().spt_host_read_png(os.fspath(path).encode(), C.byref(w), C.byref(h), C.byref(ptr)))

@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     }
     std::vector<uint8_t> rgb8(film.size());
     spt_host_film_to_rgb8(film.data(), (uint64_t)width * height, rgb8.data());
-    if (spt_host_write_png(out_path.c_str(), rgb8.data(), width, height) != SPT_OK)
+    if (spt_host_write_image(out_path.c_str(), rgb8.data(), width, height) != SPT_OK)
         std::printf("Failed to save image, err: %s\n", spt_host_last_error());  // printed and ignored, like pt.rs:292-294
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(stderr, "Finished, time used: %.3fs (%.1f Msamples/s on the GPU, %.3f ms)\n", sec,

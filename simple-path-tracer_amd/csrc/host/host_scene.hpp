@@ -48,6 +48,8 @@ struct HostScene {
 
 HostScene* load_scene_file(const std::string& path);
 void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
-void decode_png_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
+void decode_png_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);   // PNG or JPEG (by content)
+void decode_jpeg_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
+void encode_jpeg_rgb8(const uint8_t* rgb, uint32_t w, uint32_t h, int quality, std::vector<uint8_t>* out);
 
 }  // namespace spt_host

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -87,8 +88,12 @@ void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, 
 
 void decode_png_rgba8(const std::vector<uint8_t>& d, const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8 && d[2] == 0xff) {   // the content decides, as image::open's format guess does
+        decode_jpeg_rgba8(d, path, width, height, texels);
+        return;
+    }
     if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0)
-        throw HostError(SPT_HOST_ERR_UNSUPPORTED, "image '" + path + "': only PNG files are decoded (JPEG decoding is not bit-reproducible across decoders; convert the asset)");
+        throw HostError(SPT_HOST_ERR_UNSUPPORTED, "image '" + path + "': only PNG and JPEG files are decoded");
     auto be32 = [&](size_t p) { return ((uint32_t)d[p] << 24) | ((uint32_t)d[p + 1] << 16) | ((uint32_t)d[p + 2] << 8) | (uint32_t)d[p + 3]; };
     uint32_t w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte, trns;
@@ -405,6 +410,35 @@ spt_status spt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t wi
     std::fclose(f);
     if (wr != o.size()) { spt_host::set_error("short write"); return SPT_HOST_ERR_IO; }
     return SPT_OK;
+}
+
+// image.save (src/renderer/pt.rs:292-294): the extension picks the format
+spt_status spt_host_write_jpeg(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height, int32_t quality) {
+    if (!path || !rgb8 || !width || !height || width > 65535 || height > 65535) { spt_host::set_error("write_jpeg: bad argument"); return SPT_ERR_INVALID_ARG; }
+    std::vector<uint8_t> o;
+    spt_host::encode_jpeg_rgb8(rgb8, width, height, quality, &o);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { spt_host::set_error(std::string("cannot write '") + path + "'"); return SPT_HOST_ERR_IO; }
+    size_t wr = std::fwrite(o.data(), 1, o.size(), f);
+    std::fclose(f);
+    if (wr != o.size()) { spt_host::set_error("short write"); return SPT_HOST_ERR_IO; }
+    return SPT_OK;
+}
+
+spt_status spt_host_write_image(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!path) { spt_host::set_error("write_image: bad argument"); return SPT_ERR_INVALID_ARG; }
+    std::string p(path), ext;
+    const size_t dot = p.find_last_of('.');
+    if (dot != std::string::npos && p.find('/', dot) == std::string::npos)
+        for (size_t i = dot + 1; i < p.size(); ++i) ext.push_back((char)std::tolower((unsigned char)p[i]));
+    if (ext == "png") return spt_host_write_png(path, rgb8, width, height);
+    if (ext == "jpg" || ext == "jpeg") return spt_host_write_jpeg(path, rgb8, width, height, 75);   // the image crate's JpegEncoder default
+    spt_host::set_error("Failed to save image, err: the image format could not be determined from the extension of '" + p + "' (png, jpg and jpeg are written)");
+    return SPT_HOST_ERR_UNSUPPORTED;
+}
+
+spt_status spt_host_read_image(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out) {
+    return spt_host_read_png(path, width, height, rgba8_out);
 }
 
 spt_status spt_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out) {

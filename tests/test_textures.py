@@ -99,10 +99,10 @@ def test_png_decode_all_colour_types_filters_and_depths(tmp_path):
     rows = [int("".join(str(int(b)) for b in list(bitsrc[y]) + [0]), 2).to_bytes(1, "big") for y in range(h)]
     (tmp_path / "g1.png").write_bytes(png_bytes(w, h, 1, 0, rows))
     assert np.array_equal(spt.read_png(tmp_path / "g1.png")[..., 0], (bitsrc * 255).astype(np.uint8))
-    # errors: not a PNG (JPEG is deliberately not decoded), corrupt CRC, missing file
-    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(32))
+    # errors: neither PNG nor JPEG (tests/test_jpeg.py covers JPEG), corrupt CRC, missing file
+    (tmp_path / "x.gif").write_bytes(b"GIF89a" + bytes(32))
     with pytest.raises(spt.SptError) as e:
-        spt.read_png(tmp_path / "x.jpg")
+        spt.read_png(tmp_path / "x.gif")
     assert e.value.status == 103
     data = bytearray((tmp_path / "rgba.png").read_bytes())
     data[40] ^= 1
