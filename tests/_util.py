@@ -164,8 +164,11 @@ def random_rays(scene, n, seed, spread=6.0):
     spt = load_pkg()
     rng = np.random.default_rng(seed)
     inst = scene.array("instances")
-    lo = inst["bmin"].min(axis=0)
-    hi = inst["bmax"].max(axis=0)
+    if len(inst):
+        lo = inst["bmin"].min(axis=0)
+        hi = inst["bmax"].max(axis=0)
+    else:       # an empty aggregate: any rays will do, they all miss
+        lo, hi = np.full(3, -1.0, dtype=np.float32), np.full(3, 1.0, dtype=np.float32)
     c, r = (lo + hi) / 2, float(np.linalg.norm(hi - lo)) / 2 + 1e-3
     o = rng.normal(size=(n, 3))
     o = c + o / np.linalg.norm(o, axis=1, keepdims=True) * r * rng.uniform(0.2, spread, size=(n, 1))

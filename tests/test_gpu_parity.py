@@ -312,6 +312,75 @@ def test_box_filter_negative_radius_is_the_reference_nan_film(spt):
     assert np.isnan(r.render_shard(sc, spt.OutputConfig(32, 16))).all()
 
 
+def _tiny_scene(tmp_path, name, instances=True, lights=True, env=None, emissive=False):
+    import json
+    scene = {"cameras": {"type": "perspective", "name": "c", "eye": [0.0, 0.5, 4.0], "forward": [0.0, -0.1, -1.0], "up": [0.0, 1.0, 0.0], "fov": 45.0},
+             "textures": [{"type": "scalar", "name": "w", "value": [0.7, 0.6, 0.5]}],
+             "materials": [{"type": "lambert", "name": "m", "albedo": "w"}],
+             "mediums": [],
+             "surfaces": [{"name": "glow", "material": "m", "emissive": [2.0, 1.5, 1.0]}] if emissive else [],
+             "primitives": [{"type": "sphere", "name": "ball", "radius": 1.0}],
+             "instances": ([{"name": "a", "primitive": "ball", "material": "m"},
+                            {"name": "b", "primitive": "ball", **({"surface": "glow"} if emissive else {"material": "m"}), "scale": [0.4, 0.4, 0.4], "translate": [1.6, 0.8, 0.0]}]
+                           if instances else []),
+             "lights": [{"type": "point", "name": "p", "position": [2.0, 3.0, 2.0], "strength": [20.0, 20.0, 20.0]}] if lights else []}
+    if env is not None:
+        scene["environment"] = {"type": "color", "color": env}
+    path = tmp_path / (name + ".json")
+    path.write_text(json.dumps(scene))
+    return path
+
+
+@pytest.mark.parametrize("kind", ["no_instances_env", "nothing_at_all", "no_lights", "no_lights_emissive", "env_only_light"])
+def test_degenerate_scenes_match_oracle(spt, tmp_path, kind):
+    """empty aggregates and empty light lists: defined results (DESIGN D5: the reference panics with zero lights)"""
+    opts = {"no_instances_env": dict(instances=False, lights=True, env=[0.2, 0.4, 0.6]),
+            "nothing_at_all": dict(instances=False, lights=False),
+            "no_lights": dict(lights=False),
+            "no_lights_emissive": dict(lights=False, emissive=True),
+            "env_only_light": dict(lights=False, env=[0.5, 0.5, 0.5])}[kind]
+    sc = spt.load_scene(str(_tiny_scene(tmp_path, kind, **opts)))
+    r = spt.PathTracer(max_depth=4, sampler=spt.SAMPLER_RANDOM, spp=4, seed=3)
+    w, h = 37, 23                                         # not a multiple of the 16 x 16 tiles
+    ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags())
+    got = r.render_shard(sc, spt.OutputConfig(w, h))
+    _same_film(got, ref)
+    if kind == "no_instances_env":
+        assert np.array_equal(np.unique(ref.reshape(-1, 3), axis=0), np.array([[0.2, 0.4, 0.6]], dtype=np.float32))
+    if kind in ("nothing_at_all", "no_lights"):
+        assert not ref.any()
+    if kind in ("no_lights_emissive", "env_only_light"):
+        assert ref.max() > 0.1
+    rays = _util.random_rays(sc, 5000, seed=1)
+    assert _util.oracle_trace_closest(sc, rays, _util.device_oracle_flags()).tobytes() == sc.device_scene(0).trace_closest(rays).tobytes()
+
+
+@pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 1, 1), (1, 7, 3, 0), (300, 1, 2, 8), (16, 16, 1, 255)])
+def test_degenerate_render_sizes_match_oracle(spt, w, h, spp, depth):
+    sc = _scene(spt, "cfg2_cube.json")
+    r = spt.PathTracer(max_depth=depth, sampler=spt.SAMPLER_RECURRENCE, spp=spp, seed=11)
+    ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags())
+    _same_film(r.render_shard(sc, spt.OutputConfig(w, h)), ref)
+    if depth == 0:
+        assert not ref.any()            # `while curr_depth < max_depth` (pt.rs:56) never runs
+
+
+def test_more_shards_than_strips(spt):
+    sc = _scene(spt, "cfg2_cube.json")
+    r = spt.PathTracer(max_depth=3, spp=2, seed=1)
+    w, h = 40, 20
+    full = r.render_shard(sc, spt.OutputConfig(w, h))
+    seen = np.zeros(h, dtype=bool)
+    for k in range(5):                                    # 2 strips of 16 rows for 5 ranks: ranks 2 .. 4 own nothing
+        rows = spt.shard_rows(h, k, 5, 16)
+        part = r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=5, strip_rows=16)
+        assert part.shape == (len(rows), w, 3)
+        if len(rows):
+            assert np.array_equal(part.view(np.uint32), full[rows].view(np.uint32))
+        seen[rows] = True
+    assert seen.all()
+
+
 def test_render_error_paths(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=4)
