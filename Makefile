@@ -1,6 +1,7 @@
 # Builds, in-tree:
 #   simple-path-tracer_amd/lib/libspt_host.so  host side (scene JSON/OBJ/EXR -> spt_scene_desc, PNG)
 #   simple-path-tracer_amd/lib/libspt_hip.so   HIP kernels + C ABI (gfx950)
+#   simple-path-tracer_amd/lib/libspt_hip_bez.so  the same with the Bezier-patch primitive (opened by libspt_hip.so on demand)
 #   simple-path-tracer_amd/lib/spt             CLI with the reference's flags (src/main.rs:26-41)
 #   oracle/liboracle.so                        CPU oracle (test infrastructure only)
 # FP contraction is disabled everywhere so the deterministic math of
@@ -22,7 +23,7 @@ HIP_HDR  := $(wildcard $(PKG)/csrc/hip/*.h) $(wildcard include/*.h)
 all: host oracle hip cli
 
 host: $(LIBDIR)/libspt_host.so
-hip: $(LIBDIR)/libspt_hip.so
+hip: $(LIBDIR)/libspt_hip.so $(LIBDIR)/libspt_hip_bez.so
 cli: $(LIBDIR)/spt
 oracle:
 	$(MAKE) -C oracle
@@ -33,7 +34,12 @@ $(LIBDIR)/libspt_host.so: $(HOST_SRC) $(HOST_HDR)
 
 $(LIBDIR)/libspt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -Wl,-Bsymbolic -o $@ $(HIP_SRC) -ldl
+
+# the same source with the CubicBezier primitive compiled in; opened by libspt_hip.so for scenes with patches
+$(LIBDIR)/libspt_hip_bez.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DSPT_WITH_BEZIER=1 -shared -Wl,-Bsymbolic -o $@ $(HIP_SRC) -ldl
 
 $(LIBDIR)/spt: $(PKG)/csrc/cli/main.cpp $(wildcard include/*.h) $(LIBDIR)/libspt_host.so $(LIBDIR)/libspt_hip.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lspt_host -lspt_hip -Wl,-rpath,'$$ORIGIN'

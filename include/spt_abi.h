@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 7
+#define SPT_ABI_VERSION 8
 
 typedef int32_t spt_status;
 enum {
@@ -87,7 +87,13 @@ typedef struct spt_mesh {     /* one TriMesh = one BLAS (src/primitive/triangle.
     uint32_t tri_count;
 } spt_mesh;
 
-enum { SPT_PRIM_SPHERE = 0, SPT_PRIM_MESH = 1 };
+/* One bicubic Bezier patch (src/primitive/bezier.rs:19-22): cp[i][j] = control_points[i][j] (xyz, w unused);
+ * point_at(u, v) = sum_ij B_j(u) B_i(v) cp[i][j] (bezier.rs:40-44, 222-236).  The instance's box is the hull's. */
+typedef struct spt_bezier_patch {
+    float cp[4][4][4];
+} spt_bezier_patch;       /* 256 B */
+
+enum { SPT_PRIM_SPHERE = 0, SPT_PRIM_MESH = 1, SPT_PRIM_BEZIER = 2 };
 
 /* Instance = primitive + transform + surface (src/primitive/instance.rs:10-16).
  * Matrices are stored as glam stores them: three columns then the translation;
@@ -98,7 +104,7 @@ typedef struct spt_instance {
     float fwd[12];        /* trans     : object -> world                        */
     float nrm[9];         /* trans_it = transpose(inverse(M).matrix3), 3 columns */
     uint32_t prim_type;   /* SPT_PRIM_*                                          */
-    uint32_t prim_id;     /* sphere index or mesh index                          */
+    uint32_t prim_id;     /* sphere, mesh or Bezier-patch index                  */
     uint32_t surface;     /* index into surfaces                                 */
     int32_t light;        /* index of this instance's ShapeLight in lights, -1 if not emissive
                              (instance_light_map, src/core/scene_resources.rs:112-120) */
@@ -264,6 +270,8 @@ typedef struct spt_scene_desc {
     uint32_t n_image_levels;      const spt_image_level* image_levels;
     uint32_t n_texels;            const uint32_t* texels;
     uint32_t n_material_recipes;  const spt_material_recipe* material_recipes;
+    /* bicubic Bezier patches (instances with prim_type SPT_PRIM_BEZIER) */
+    uint32_t n_bezier_patches;    const spt_bezier_patch* bezier_patches;
 } spt_scene_desc;
 
 /* PerspectiveCamera after ::new (src/camera/perspective.rs:15-27). */

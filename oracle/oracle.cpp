@@ -320,6 +320,225 @@ inline bool sphere_intersect_test(const Ctx& cx, uint32_t si, const Ray& ray, fl
     return false;
 }
 
+// ---------------------------------------------------------------- src/primitive/bezier.rs (Bezier clipping build)
+// glam 0.20 Vec2 (scalar): dot = x*x + y*y, normalize = v * (1 / length), Vec2 / f32 divides each component
+struct V2 { float x, y; };
+inline V2 operator+(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
+inline V2 operator-(V2 a, V2 b) { return {a.x - b.x, a.y - b.y}; }
+inline V2 operator*(V2 a, float s) { return {a.x * s, a.y * s}; }
+inline V2 operator/(V2 a, float s) { return {a.x / s, a.y / s}; }
+inline V2 normalize2(V2 a) { return a * (1.0f / spt_sqrt(a.x * a.x + a.y * a.y)); }
+struct Patch2 { V2 p[4][4]; };
+struct OptF { bool some; float v; };
+
+constexpr uint32_t CLIPPING_MAX_TIMES = 16;    // bezier.rs:14-17
+constexpr float CLIPPING_EPS = 0.00001f;
+
+inline void cubic_bezier_at(float u, float* b) {      // bezier.rs:206-209
+    float iu = 1.0f - u;
+    b[0] = iu * iu * iu; b[1] = 3.0f * iu * iu * u; b[2] = 3.0f * u * u * iu; b[3] = u * u * u;
+}
+inline void cubic_bezier_du_at(float u, float* b) {   // bezier.rs:211-219
+    float iu = 1.0f - u;
+    b[0] = -3.0f * iu * iu;
+    b[1] = 3.0f * iu * iu - 6.0f * iu * u;
+    b[2] = 6.0f * u * iu - 3.0f * u * u;
+    b[3] = 3.0f * u * u;
+}
+inline Vec3 cubic_bezier_sum(const spt_bezier_patch& bp, const float* bu, const float* bv) {   // bezier.rs:222-236
+    Vec3 result = v3(0, 0, 0);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) result = result + v3(bp.cp[i][j]) * (bu[j] * bv[i]);
+    return result;
+}
+inline Vec3 bezier_point_at(const spt_bezier_patch& bp, float u, float v) {      // bezier.rs:40-44
+    float bu[4], bv[4];
+    cubic_bezier_at(u, bu); cubic_bezier_at(v, bv);
+    return cubic_bezier_sum(bp, bu, bv);
+}
+inline Vec3 bezier_tangent_at(const spt_bezier_patch& bp, float u, float v) {    // bezier.rs:46-50
+    float bu[4], bv[4];
+    cubic_bezier_du_at(u, bu); cubic_bezier_at(v, bv);
+    return cubic_bezier_sum(bp, bu, bv);
+}
+inline Vec3 bezier_bitangent_at(const spt_bezier_patch& bp, float u, float v) {  // bezier.rs:52-56
+    float bu[4], bv[4];
+    cubic_bezier_at(u, bu); cubic_bezier_du_at(v, bv);
+    return cubic_bezier_sum(bp, bu, bv);
+}
+inline void clip_bezier_by(const V2* pt, float u_min, float u_max, V2* out) {     // bezier.rs:425-455
+    float b[4];
+    cubic_bezier_at(u_min, b);
+    V2 p_min = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
+    cubic_bezier_du_at(u_min, b);
+    V2 d_min = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
+    d_min = d_min * (u_max - u_min);
+    cubic_bezier_at(u_max, b);
+    V2 p_max = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
+    cubic_bezier_du_at(u_max, b);
+    V2 d_max = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
+    d_max = d_max * (u_max - u_min);
+    out[0] = p_min; out[1] = p_min + d_min / 3.0f; out[2] = p_max - d_max / 3.0f; out[3] = p_max;
+}
+inline void clip_bezier_at_midpoint(const V2* pt, V2* l, V2* r) {                // bezier.rs:458-485
+    float b[4];
+    cubic_bezier_at(0.5f, b);
+    V2 p_mid = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
+    cubic_bezier_du_at(0.5f, b);
+    V2 d_mid = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
+    d_mid = d_mid * 0.5f / 3.0f;
+    l[0] = pt[0]; l[1] = (pt[0] + pt[1]) * 0.5f; l[2] = p_mid - d_mid; l[3] = p_mid;
+    r[0] = p_mid; r[1] = p_mid + d_mid; r[2] = (pt[2] + pt[3]) * 0.5f; r[3] = pt[3];
+}
+inline Patch2 transposed(const V2 rows[4][4]) {   // the `swap` re-indexing of bezier.rs:307-318, 381-386
+    Patch2 o;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) o.p[a][b] = rows[b][a];
+    return o;
+}
+// bezier.rs:239-422, the recursion as written; results are appended in the reference's order
+void bezier_clipping(const Patch2& patch, V2 lu, V2 lv, float au0, float au1, float av0, float av1, bool real_u, OptF calculated,
+                     uint32_t times, std::vector<V2>& results) {
+    if (times == CLIPPING_MAX_TIMES) {
+        float u = 0.5f * au0 + au1;
+        float v = calculated.some ? calculated.v : 0.5f * av0 + av1;
+        results.push_back(real_u ? V2{u, v} : V2{v, u});
+        return;
+    }
+    float upper[4] = {0, 0, 0, 0}, lower[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float dist = patch.p[i][j].x * lu.y - patch.p[i][j].y * lu.x;
+            if (i == 0 || dist > upper[j]) upper[j] = dist;
+            if (i == 0 || dist < lower[j]) lower[j] = dist;
+        }
+    static const int pairs[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+    float u_min = (upper[0] >= 0.0f && lower[0] <= 0.0f) ? 0.0f : 1.0f;
+    float u_max = (upper[3] >= 0.0f && lower[3] <= 0.0f) ? 1.0f : 0.0f;
+    for (const auto& pr : pairs) {
+        const int a = pr[0], b = pr[1];
+        if (upper[a] * upper[b] <= 0.0f) {
+            float diff = upper[b] - upper[a];
+            if (diff == 0.0f) {
+                u_min = spt_min(u_min, (float)a / 3.0f);
+                u_max = spt_max(u_max, (float)b / 3.0f);
+            } else {
+                float k = (float)(b - a) / 3.0f / diff;
+                float c = (float)a / 3.0f - k * upper[a];
+                u_min = spt_min(u_min, c);
+                u_max = spt_max(u_max, c);
+            }
+        }
+        if (lower[a] * lower[b] <= 0.0f) {
+            float diff = lower[b] - lower[a];
+            if (diff == 0.0f) {
+                u_min = spt_min(u_min, (float)a / 3.0f);
+                u_max = spt_max(u_max, (float)b / 3.0f);
+            } else {
+                float k = (float)(b - a) / 3.0f / diff;
+                float c = (float)b / 3.0f - k * lower[b];
+                u_min = spt_min(u_min, c);
+                u_max = spt_max(u_max, c);
+            }
+        }
+    }
+    if (u_max < u_min) return;
+    const bool swap = !calculated.some;
+    if (u_max - u_min > 0.8f) {
+        V2 l[4][4], r[4][4];
+        for (int k = 0; k < 4; ++k) clip_bezier_at_midpoint(patch.p[k], l[k], r[k]);
+        if (swap) {
+            bezier_clipping(transposed(l), lv, lu, av0, av1, au0 * 0.5f, au1, !real_u, OptF{false, 0.0f}, times + 1, results);
+            bezier_clipping(transposed(r), lv, lu, av0, av1, au0 * 0.5f, au0 * 0.5f + au1, !real_u, OptF{false, 0.0f}, times + 1, results);
+        } else {
+            Patch2 pl, prr;
+            std::memcpy(pl.p, l, sizeof l); std::memcpy(prr.p, r, sizeof r);
+            bezier_clipping(pl, lu, lv, au0 * 0.5f, au1, av0, av1, real_u, calculated, times + 1, results);
+            bezier_clipping(prr, lu, lv, au0 * 0.5f, au0 * 0.5f + au1, av0, av1, real_u, calculated, times + 1, results);
+        }
+        return;
+    }
+    float u_len = u_max - u_min;
+    bool stop = u_len * au0 < CLIPPING_EPS;
+    if (stop) {
+        float u = 0.5f * (u_max + u_min) * au0 + au1;
+        if (calculated.some) {
+            results.push_back(real_u ? V2{u, calculated.v} : V2{calculated.v, u});
+            return;
+        }
+        calculated = OptF{true, u};
+    }
+    V2 n[4][4];
+    for (int k = 0; k < 4; ++k) clip_bezier_by(patch.p[k], u_min, u_max, n[k]);
+    if (swap) {
+        bezier_clipping(transposed(n), lv, lu, av0, av1, au0 * u_len, au0 * u_min + au1, !real_u, calculated, times + 1, results);
+    } else {
+        Patch2 pn;
+        std::memcpy(pn.p, n, sizeof n);
+        bezier_clipping(pn, lu, lv, au0 * u_len, au0 * u_min + au1, av0, av1, real_u, calculated, times + 1, results);
+    }
+}
+// bezier.rs:105-134: (u, v, t) of the nearest accepted intersection
+inline bool bezier_intersect_ray(const Ctx& cx, uint32_t bi, const Ray& ray, float* u_out, float* v_out, float* t_out) {
+    cx.c->spheres++;
+    const spt_bezier_patch& bp = cx.d->bezier_patches[bi];
+    Vec3 n1 = normalize(v3(-ray.direction.y, ray.direction.x, 0.0f));
+    Vec3 n2 = normalize(v3(0.0f, -ray.direction.z, ray.direction.y));
+    Patch2 patch;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            Vec3 diff = v3(bp.cp[i][j]) - ray.origin;
+            patch.p[i][j] = V2{dot(diff, n1), dot(diff, n2)};
+        }
+    V2 lu = normalize2((patch.p[3][0] - patch.p[0][0]) + (patch.p[3][3] - patch.p[0][3]));
+    V2 lv = normalize2((patch.p[0][3] - patch.p[0][0]) + (patch.p[3][3] - patch.p[3][0]));
+    std::vector<V2> inters;
+    bezier_clipping(patch, lu, lv, 1.0f, 0.0f, 1.0f, 0.0f, true, OptF{false, 0.0f}, 0, inters);
+    float t_min = SPT_F32_MAX;
+    bool found = false;
+    for (const V2& it : inters) {
+        Vec3 p = bezier_point_at(bp, it.x, it.y);
+        Vec3 diff = p - ray.origin;
+        Vec3 c = cross(diff, ray.direction);
+        if (length_squared(c) < CLIPPING_EPS) {
+            float t = dot(diff, ray.direction) / length_squared(ray.direction);
+            if (t > ray.t_min && t < t_min) {
+                t_min = t;
+                *u_out = it.x; *v_out = it.y; *t_out = t;
+                found = true;
+            }
+        }
+    }
+    return found;
+}
+// bezier.rs:160-174
+inline bool bezier_intersect(const Ctx& cx, uint32_t bi, const Ray& ray, Inter& inter) {
+    float u, v, t;
+    if (bezier_intersect_ray(cx, bi, ray, &u, &v, &t)) {
+        if (t > ray.t_min && closer(cx, t, (int32_t)bi, inter)) {
+            const spt_bezier_patch& bp = cx.d->bezier_patches[bi];
+            inter.t = t;
+            inter.texcoords[0] = u; inter.texcoords[1] = v;
+            inter.tangent = bezier_tangent_at(bp, u, v);
+            inter.bitangent = bezier_bitangent_at(bp, u, v);
+            inter.normal = normalize(cross(inter.tangent, inter.bitangent));
+            inter.prim = (int32_t)bi;
+            inter.instance = inter.cand_instance;
+            inter.prim_type = SPT_PRIM_BEZIER;
+            inter.bv = u;      // the hit record carries the patch parameters where a triangle has its barycentrics
+            inter.bw = v;
+            return true;
+        }
+    }
+    return false;
+}
+// bezier.rs:152-158
+inline bool bezier_intersect_test(const Ctx& cx, uint32_t bi, const Ray& ray, float t_max) {
+    float u, v, t;
+    if (bezier_intersect_ray(cx, bi, ray, &u, &v, &t)) return t > ray.t_min && t < t_max;
+    return false;
+}
+
 // ---------------------------------------------------------------- src/primitive/bvh.rs:237-283 over a BLAS
 constexpr int STACK_MAX = 128;
 inline bool blas_intersect(const Ctx& cx, const spt_mesh& mesh, const Ray& ray, Inter& inter) {
@@ -382,8 +601,9 @@ inline bool instance_intersect(const Ctx& cx, uint32_t ii, const Ray& ray, Inter
     const spt_instance& in = cx.d->instances[ii];
     Ray tr = transformed_by(ray, in.inv);
     inter.cand_instance = (int32_t)ii;
-    bool hit = (in.prim_type == SPT_PRIM_SPHERE) ? sphere_intersect(cx, in.prim_id, tr, inter)
-                                                 : blas_intersect(cx, cx.d->meshes[in.prim_id], tr, inter);
+    bool hit = (in.prim_type == SPT_PRIM_SPHERE)   ? sphere_intersect(cx, in.prim_id, tr, inter)
+               : (in.prim_type == SPT_PRIM_BEZIER) ? bezier_intersect(cx, in.prim_id, tr, inter)
+                                                   : blas_intersect(cx, cx.d->meshes[in.prim_id], tr, inter);
     if (hit) {
         inter.instance = (int32_t)ii;
         inter.position = point_at(ray, inter.t);
@@ -398,8 +618,9 @@ inline bool instance_intersect_test(const Ctx& cx, uint32_t ii, const Ray& ray, 
     cx.c->insts++;
     const spt_instance& in = cx.d->instances[ii];
     Ray tr = transformed_by(ray, in.inv);
-    return (in.prim_type == SPT_PRIM_SPHERE) ? sphere_intersect_test(cx, in.prim_id, tr, t_max)
-                                             : blas_intersect_test(cx, cx.d->meshes[in.prim_id], tr, t_max);
+    return (in.prim_type == SPT_PRIM_SPHERE)   ? sphere_intersect_test(cx, in.prim_id, tr, t_max)
+           : (in.prim_type == SPT_PRIM_BEZIER) ? bezier_intersect_test(cx, in.prim_id, tr, t_max)
+                                               : blas_intersect_test(cx, cx.d->meshes[in.prim_id], tr, t_max);
 }
 
 // ---------------------------------------------------------------- scene.aggregate(): Group (group.rs:24-40) or BvhAccel<Instance>
@@ -1587,6 +1808,7 @@ inline Ray shadow_ray_from_medium(const Ctx& cx, Vec3 p, Vec3 light_dir, float l
     bool hit = false;
     if (prim_type == SPT_PRIM_MESH) hit = triangle_intersect(cx, (uint32_t)prim, shadow_ray, temp);
     else if (prim_type == SPT_PRIM_SPHERE) hit = sphere_intersect(cx, (uint32_t)prim, shadow_ray, temp);
+    else if (prim_type == SPT_PRIM_BEZIER) hit = bezier_intersect(cx, (uint32_t)prim, shadow_ray, temp);
     if (hit) {
         *transported = temp.t;
         shadow_ray.t_min += temp.t;

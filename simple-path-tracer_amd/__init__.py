@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 7
+SPT_ABI_VERSION = 8
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -59,6 +59,10 @@ class TriAttr(C.Structure):
 
 class Sphere(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("radius", C.c_float)]
+
+
+class BezierPatch(C.Structure):
+    _fields_ = [("cp", ((C.c_float * 4) * 4) * 4)]
 
 
 class Mesh(C.Structure):
@@ -141,6 +145,7 @@ class SceneDesc(C.Structure):
         ("n_image_levels", C.c_uint32), ("image_levels", C.POINTER(ImageLevel)),
         ("n_texels", C.c_uint32), ("texels", C.POINTER(C.c_uint32)),
         ("n_material_recipes", C.c_uint32), ("material_recipes", C.POINTER(MaterialRecipe)),
+        ("n_bezier_patches", C.c_uint32), ("bezier_patches", C.POINTER(BezierPatch)),
     ]
 
 
@@ -289,6 +294,7 @@ class Scene:
             "textures": (d.textures, d.n_textures, Texture), "images": (d.images, d.n_images, Image),
             "image_levels": (d.image_levels, d.n_image_levels, ImageLevel), "texels": (d.texels, d.n_texels, C.c_uint32),
             "material_recipes": (d.material_recipes, d.n_material_recipes, MaterialRecipe),
+            "bezier_patches": (d.bezier_patches, d.n_bezier_patches, BezierPatch),
         }
         ptr, n, ty = table[field]
         if n == 0:

@@ -10,6 +10,12 @@
 
 #define SPT_DEV __device__ __forceinline__
 
+// 1 only in libspt_hip_bez.so: the CubicBezier primitive (bezier.h) in the walkers, the hit reconstruction and the
+// medium probe.  The plain library never sees a scene with patches (spt_scene_create hands those over).
+#ifndef SPT_WITH_BEZIER
+#define SPT_WITH_BEZIER 0
+#endif
+
 struct f3 {
     float x, y, z;
 };

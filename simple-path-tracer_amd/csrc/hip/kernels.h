@@ -460,6 +460,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         if (does_hit && it.prim_type == SPT_PRIM_MESH) {
                             float t, v, w;
                             if (tri_test(sc.tri_pos, (uint32_t)h.prim, sr, &t, &v, &w) && t > sr.t_min && t < probe_max) { probe_hit = true; probe_t = t; }
+#if SPT_WITH_BEZIER
+                        } else if (does_hit && it.prim_type == SPT_PRIM_BEZIER) {
+                            float u, v, t;
+                            if (bezier_intersect_ray(sc.bez + 16u * it.prim_id, sr, &u, &v, &t) && t > sr.t_min && t < probe_max) { probe_hit = true; probe_t = t; }
+#endif
                         } else if (does_hit) {
                             float mn, mx;
                             if (sphere_roots(sc.spheres[it.prim_id], sr, &mn, &mx)) {

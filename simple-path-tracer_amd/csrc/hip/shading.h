@@ -125,6 +125,15 @@ SPT_DEV DInter reconstruct_hit(const DScene& sc, const DRay& ray, const DHit& h)
         n = (point_at(orr, h.t) - mk3(s)) / s.w;
         sphere_frame(n, &tg, &bt);
         if (kTex) sphere_normal_to_texcoords(n, it.uv);
+#if SPT_WITH_BEZIER
+    } else if (in.prim_type == SPT_PRIM_BEZIER) {   // bezier.rs:163-168: (u, v) came with the hit record
+        float4 cp[16];
+        for (int k = 0; k < 16; ++k) cp[k] = sc.bez[16u * in.prim_id + (uint32_t)k];
+        tg = bezier_tangent_at(cp, h.v, h.w);
+        bt = bezier_bitangent_at(cp, h.v, h.w);
+        n = normalize(cross(tg, bt));
+        it.uv[0] = h.v; it.uv[1] = h.w;
+#endif
     } else {
         float4 q[kTex ? 9 : 7];
 #pragma unroll

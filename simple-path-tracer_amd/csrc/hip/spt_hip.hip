@@ -2,6 +2,7 @@
 // Host code here only validates descriptors, moves the flattened scene into HBM
 // and enqueues kernels on one HIP stream; there is no CPU rendering path.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -468,13 +469,29 @@ uint32_t build_n4(const spt_bvh_node* nodes, uint32_t root, std::vector<float4>&
 
 }  // namespace
 
+// Scenes with Bezier patches are served by libspt_hip_bez.so: this same source compiled with SPT_WITH_BEZIER=1 (the
+// patch test of csrc/hip/bezier.h keeps a 16-frame subdivision stack in scratch memory, and a kernel that can call it
+// pays for that scratch on every wave whether or not the scene has patches).  spt_scene_create of the plain library
+// opens the other one next to itself and every later call on that scene is passed through.
+struct BezierLib {
+    void* handle = nullptr;
+    spt_status (*create)(const spt_scene_desc*, int32_t, spt_scene**) = nullptr;
+    void (*destroy)(spt_scene*) = nullptr;
+    spt_status (*render)(const spt_scene*, const spt_camera*, const spt_render_params*, float*, spt_render_stats*) = nullptr;
+    spt_status (*trace_closest)(const spt_scene*, uint32_t, const spt_ray*, spt_hit*) = nullptr;
+    spt_status (*trace_any)(const spt_scene*, uint32_t, const spt_ray*, uint8_t*) = nullptr;
+    const char* (*last_error)(void) = nullptr;
+};
+
 struct spt_scene {
+    const BezierLib* fwd = nullptr;   // set: `inner` lives in libspt_hip_bez.so and nothing below is used
+    spt_scene* inner = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: k_shadow(b) next to k_extend(b) (see spt_render)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DScene d{};
-    DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, surfaces, materials, mediums, lights;
+    DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, bezier, surfaces, materials, mediums, lights;
     DeviceBuffer light_props, light_u, light_k, env_px, env_uk, geo;
     bool lds_geo = false;   // traversal geometry small enough to live in LDS (k_*<true>)
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
@@ -494,6 +511,7 @@ struct spt_scene {
     DeviceBuffer textures, tex_prog, tex_root, tex_chain, images, image_levels, texels, recipes;
     std::vector<hipEvent_t> events;
     ~spt_scene() {
+        if (fwd) { fwd->destroy(inner); return; }
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -518,6 +536,7 @@ void validate(const spt_scene_desc& s) {
     need(s.tri_pos, s.n_tris, "tri_pos");
     need(s.tri_attr, s.n_tris, "tri_attr");
     need(s.spheres, s.n_spheres, "spheres");
+    need(s.bezier_patches, s.n_bezier_patches, "bezier_patches");
     need(s.surfaces, s.n_surfaces, "surfaces");
     need(s.materials, s.n_materials, "materials");
     need(s.mediums, s.n_mediums, "mediums");
@@ -530,6 +549,10 @@ void validate(const spt_scene_desc& s) {
             if (in.prim_id >= s.n_spheres) fail(SPT_ERR_INVALID_ARG, "scene desc: instance sphere index out of range");
         } else if (in.prim_type == SPT_PRIM_MESH) {
             if (in.prim_id >= s.n_meshes) fail(SPT_ERR_INVALID_ARG, "scene desc: instance mesh index out of range");
+        } else if (in.prim_type == SPT_PRIM_BEZIER) {
+            if (in.prim_id >= s.n_bezier_patches) fail(SPT_ERR_INVALID_ARG, "scene desc: instance Bezier patch index out of range");
+            // CubicBezier::sample / pdf / surface_area are `unimplemented!` in the reference (bezier.rs:180-190)
+            if (in.light >= 0) fail(SPT_ERR_UNSUPPORTED, "scene desc: a Bezier patch cannot be a shape light");
         } else {
             fail(SPT_ERR_INVALID_ARG, "scene desc: bad instance prim_type");
         }
@@ -625,6 +648,41 @@ constexpr uint32_t kPersistentBlocks = 2048;
 
 }  // namespace
 
+extern "C" uint32_t spt_abi_version(void);
+
+#if !SPT_WITH_BEZIER
+namespace {
+const BezierLib* bezier_lib() {
+    static BezierLib lib;
+    static std::once_flag once;
+    static std::string err;
+    std::call_once(once, [] {
+        Dl_info info;
+        if (!dladdr(reinterpret_cast<void*>(&spt_abi_version), &info) || !info.dli_fname) { err = "dladdr failed"; return; }
+        std::string path(info.dli_fname);
+        const size_t slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "libspt_hip_bez.so";
+        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { const char* e = dlerror(); err = e ? e : "dlopen failed"; return; }
+        lib.create = reinterpret_cast<decltype(lib.create)>(dlsym(h, "spt_scene_create"));
+        lib.destroy = reinterpret_cast<decltype(lib.destroy)>(dlsym(h, "spt_scene_destroy"));
+        lib.render = reinterpret_cast<decltype(lib.render)>(dlsym(h, "spt_render"));
+        lib.trace_closest = reinterpret_cast<decltype(lib.trace_closest)>(dlsym(h, "spt_trace_closest"));
+        lib.trace_any = reinterpret_cast<decltype(lib.trace_any)>(dlsym(h, "spt_trace_any"));
+        lib.last_error = reinterpret_cast<decltype(lib.last_error)>(dlsym(h, "spt_last_error"));
+        auto version = reinterpret_cast<uint32_t (*)(void)>(dlsym(h, "spt_abi_version"));
+        if (!lib.create || !lib.destroy || !lib.render || !lib.trace_closest || !lib.trace_any || !lib.last_error || !version || version() != SPT_ABI_VERSION) {
+            err = path + " does not export ABI version " + std::to_string(SPT_ABI_VERSION);
+            return;
+        }
+        lib.handle = h;
+    });
+    if (!lib.handle) fail(SPT_ERR_UNSUPPORTED, "the scene has Bezier patches and libspt_hip_bez.so could not be loaded: " + err);
+    return &lib;
+}
+}  // namespace
+#endif
+
 extern "C" {
 
 const char* spt_last_error(void) { return g_error.c_str(); }
@@ -647,6 +705,19 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
     *out = nullptr;
     spt_scene* sc = nullptr;
     try {
+#if !SPT_WITH_BEZIER
+        if (desc->n_bezier_patches > 0) {   // see BezierLib
+            const BezierLib* lib = bezier_lib();
+            spt_scene* inner = nullptr;
+            const spt_status st = lib->create(desc, device, &inner);
+            if (st != SPT_OK) fail(st, lib->last_error());
+            sc = new spt_scene();
+            sc->fwd = lib;
+            sc->inner = inner;
+            *out = sc;
+            return SPT_OK;
+        }
+#endif
         validate(*desc);
         int n = usable_device_count();
         if (n <= 0) fail(SPT_ERR_NO_DEVICE, "no HIP device is visible: libspt_hip has no CPU fallback");
@@ -680,6 +751,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         sc->instances.upload(s.instances, s.n_instances);
         sc->meshes.upload(s.meshes, s.n_meshes);
         sc->spheres.upload(s.spheres, s.n_spheres);
+        sc->bezier.upload(s.bezier_patches, s.n_bezier_patches);
         sc->surfaces.upload(s.surfaces, s.n_surfaces);
         sc->materials.upload(s.materials, s.n_materials);
         sc->mediums.upload(s.mediums, s.n_mediums);
@@ -707,6 +779,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         d.instances = sc->instances.as<float4>();
         d.meshes = sc->meshes.as<uint4>();
         d.spheres = sc->spheres.as<float4>();
+        d.bez = sc->bezier.as<float4>();
         d.surfaces = sc->surfaces.as<spt_surface>();
         d.materials = sc->materials.as<spt_material>();
         d.mediums = sc->mediums.as<spt_medium>();
@@ -983,6 +1056,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                       float* rgb_mean_out, spt_render_stats* stats) {
     if (!scene_c || !cam || !params || !rgb_mean_out) { g_error = "render: null argument"; return SPT_ERR_INVALID_ARG; }
     spt_scene* sc = const_cast<spt_scene*>(scene_c);
+    if (sc->fwd) {
+        const spt_status st = sc->fwd->render(sc->inner, cam, params, rgb_mean_out, stats);
+        if (st != SPT_OK) g_error = sc->fwd->last_error();
+        return st;
+    }
     std::lock_guard<std::mutex> lock(sc->mu);
     try {
         const spt_render_params& p = *params;
@@ -1394,6 +1472,12 @@ static spt_status trace_common(const spt_scene* scene_c, uint32_t n, const spt_r
     if (!scene_c || (n && (!rays || !out))) { g_error = "trace: null argument"; return SPT_ERR_INVALID_ARG; }
     if (n == 0) return SPT_OK;
     spt_scene* sc = const_cast<spt_scene*>(scene_c);
+    if (sc->fwd) {
+        const spt_status st = closest ? sc->fwd->trace_closest(sc->inner, n, rays, static_cast<spt_hit*>(out))
+                                      : sc->fwd->trace_any(sc->inner, n, rays, static_cast<uint8_t*>(out));
+        if (st != SPT_OK) g_error = sc->fwd->last_error();
+        return st;
+    }
     std::lock_guard<std::mutex> lock(sc->mu);
     try {
         HIP_CHECK(hipSetDevice(sc->device));

@@ -17,6 +17,7 @@
 // divisions per node; it only culls, the returned hit is unaffected.
 #pragma once
 #include "device_math.h"
+#include "bezier.h"
 
 struct DScene {
     const float4* tri_pos;     // 3 x float4 per triangle
@@ -24,6 +25,7 @@ struct DScene {
     const float4* instances;   // 12 x float4 per instance (spt_instance)
     const uint4* meshes;       // root, node_count, tri_first, tri_count
     const float4* spheres;     // center, radius
+    const float4* bez;         // Bezier patches: 16 control points (xyz) per patch; only read by libspt_hip_bez.so
     const spt_surface* surfaces;
     const spt_material* materials;
     const spt_medium* mediums;
@@ -392,6 +394,16 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
         }
         return;
     }
+#if SPT_WITH_BEZIER
+    if (prim_type == SPT_PRIM_BEZIER) {   // bezier.rs:160-174; the patch parameters ride in the hit's (v, w)
+        float u, v, t;
+        if (bezier_intersect_ray(sc.bez + 16u * prim_id, orr, &u, &v, &t) && t > orr.t_min &&
+            (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)prim_id, h)))) {
+            h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)prim_id; h.v = u; h.w = v;
+        }
+        return;
+    }
+#endif
     const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
     const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(sc, orr.d);
@@ -417,6 +429,12 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
         float mn, mx;
         return sphere_roots(geo_ld<kLds>(sc, sc.o_sph + prim_id), orr, &mn, &mx) && mn < t_max && mx > orr.t_min;  // sphere.rs:51-56
     }
+#if SPT_WITH_BEZIER
+    if (prim_type == SPT_PRIM_BEZIER) {   // bezier.rs:152-158
+        float u, v, t;
+        return bezier_intersect_ray(sc.bez + 16u * prim_id, orr, &u, &v, &t) && t > orr.t_min && t < t_max;
+    }
+#endif
     const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);
     const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(sc, orr.d);
@@ -620,6 +638,21 @@ struct Walker {
                 }
                 return;
             }
+#if SPT_WITH_BEZIER
+            if (prim_type == SPT_PRIM_BEZIER) {
+                float u, v, t;
+                const bool got = bezier_intersect_ray(sc.bez + 16u * prim_id, orr, &u, &v, &t) && t > orr.t_min;
+                if (kClosest) {
+                    if (got && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, (int32_t)prim_id, h)))) {
+                        h.t = t; h.inst = (int32_t)inst; h.prim = (int32_t)prim_id; h.v = u; h.w = v;
+                    }
+                } else if (got && t < h.t) {
+                    h.inst = (int32_t)inst;
+                    done = true;
+                }
+                return;
+            }
+#endif
             oo = orr.o; od = orr.d;
             inv_o = recip3(sc, orr.d);
             const float4 rlo = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id), rhi = geo_ld<kLds>(sc, sc.o_mesh + 2u * prim_id + 1u);

@@ -23,6 +23,7 @@ struct HostScene {
     std::vector<spt_tri_pos> tri_pos;
     std::vector<spt_tri_attr> tri_attr;
     std::vector<spt_sphere> spheres;
+    std::vector<spt_bezier_patch> bezier_patches;
     std::vector<spt_surface> surfaces;
     std::vector<spt_material> materials;
     std::vector<spt_medium> mediums;

@@ -128,6 +128,25 @@ class Params {
         visited_.insert(k);
         return out;
     }
+    // get_float_3darray (loader.rs:201-262) with all three lengths given; `stride` floats per innermost row in `out`
+    void get_float_3darray(const std::string& k, size_t n1, size_t n2, size_t n3, float* out, size_t stride) {
+        const JsonValue* v = find(k);
+        const std::string what = "3D array with " + std::to_string(n1) + "x" + std::to_string(n2) + "x" + std::to_string(n3) + " floats";
+        if (v->kind != JsonValue::Array || v->arr.size() != n1) bad(k, what.c_str());
+        for (size_t a = 0; a < n1; ++a) {
+            const JsonValue& v2 = v->arr[a];
+            if (v2.kind != JsonValue::Array || v2.arr.size() != n2) bad(k, what.c_str());
+            for (size_t b = 0; b < n2; ++b) {
+                const JsonValue& v3 = v2.arr[b];
+                if (v3.kind != JsonValue::Array || v3.arr.size() != n3) bad(k, what.c_str());
+                for (size_t c = 0; c < n3; ++c) {
+                    if (v3.arr[c].kind != JsonValue::Float) bad(k, what.c_str());
+                    out[(a * n2 + b) * stride + c] = (float)v3.arr[c].f;
+                }
+            }
+        }
+        visited_.insert(k);
+    }
     // get_matrix (loader.rs:307-335): 16 values column-major; non-Float entries keep identity.
     Affine get_matrix(const std::string& k) {
         const JsonValue* v = find(k);
@@ -804,7 +823,17 @@ struct SceneBuilder {
             calc_tangents(m);
             rec.type = SPT_PRIM_MESH;
             rec.id = add_mesh(m, rec.box);
-        } else if (ty == "cubic_bezier" || ty == "catmull_clark") {
+        } else if (ty == "cubic_bezier") {
+            // CubicBezier::load / ::new (src/primitive/bezier.rs:24-38, 136-148): 4 x 4 control points, the box of the hull
+            spt_bezier_patch bp;
+            std::memset(&bp, 0, sizeof bp);
+            p.get_float_3darray("control_points", 4, 4, 3, &bp.cp[0][0][0], 4);
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) rec.box.grow(V3{bp.cp[i][j][0], bp.cp[i][j][1], bp.cp[i][j][2]});
+            rec.type = SPT_PRIM_BEZIER;
+            rec.id = (uint32_t)hs.bezier_patches.size();
+            hs.bezier_patches.push_back(bp);
+        } else if (ty == "catmull_clark") {
             if (prims.count(name) || unsupported_prims.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated primitive name '" + name + "'");
             unsupported_prims[name] = p.name() + ": primitive type '" + ty + "' is outside the hot-path scope (SURVEY 2 #4)";
             return;
@@ -1482,6 +1511,8 @@ struct SceneBuilder {
 
     float instance_area(const InstRec& r) {
         const spt_instance& in = r.inst;
+        if (in.prim_type == SPT_PRIM_BEZIER)   // the reference reaches `unimplemented!` (bezier.rs:188-190) when it builds the ShapeLight
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "instance '" + r.name + "': an emissive surface on a cubic_bezier primitive (CubicBezier::surface_area is unimplemented in the reference)");
         if (in.prim_type == SPT_PRIM_SPHERE) {
             float rad = hs.spheres[in.prim_id].radius * 0.5f;
             V3 v0 = r.trans.vector({-rad, -rad, -rad}), v1 = r.trans.vector({-rad, -rad, rad});
@@ -1599,6 +1630,7 @@ void HostScene::finalize_desc() {
     desc.n_blas_nodes = (uint32_t)blas_nodes.size(); desc.blas_nodes = blas_nodes.data();
     desc.n_tris = (uint32_t)tri_pos.size(); desc.tri_pos = tri_pos.data(); desc.tri_attr = tri_attr.data();
     desc.n_spheres = (uint32_t)spheres.size(); desc.spheres = spheres.data();
+    desc.n_bezier_patches = (uint32_t)bezier_patches.size(); desc.bezier_patches = bezier_patches.data();
     desc.n_surfaces = (uint32_t)surfaces.size(); desc.surfaces = surfaces.data();
     desc.n_materials = (uint32_t)materials.size(); desc.materials = materials.data();
     desc.n_mediums = (uint32_t)mediums.size(); desc.mediums = mediums.data();

@@ -28,7 +28,7 @@ def _scene(spt, name):
     return spt.load_scene(os.path.join(_util.SCENES, name))
 
 
-@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json", "t_gltf.gltf", "t_subsurface.json"])
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json", "t_gltf.gltf", "t_subsurface.json", "t_bezier.json"])
 def test_trace_closest_and_any_bit_exact(spt, scene_name):
     sc = _scene(spt, scene_name)
     rays = _util.random_rays(sc, 200_000, seed=11)
@@ -96,6 +96,8 @@ def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
     ("t_textured.json", None, "recurrence"),     #   mode, sRGB, binary ops, normal + emissive maps, per-hit material recipes
     ("t_gltf.gltf", "cam", "random"),            # glTF import: metallic-roughness (G / B channels), spec-gloss (alpha), punctual lights
     ("t_subsurface.json", None, "random"),       # Subsurface substrate: BSSRDF probe rays, rough / smooth coat, image-backed albedo
+    ("t_bezier.json", "main", "random"),         # bicubic Bezier patches (libspt_hip_bez.so): clipping, (u, v) texcoords, glass seen from
+    ("t_bezier.json", "low", "recurrence"),      #   both sides, a medium boundary on a patch (its light samples probe the patch)
 ])
 def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     sc = _scene(spt, scene_name)

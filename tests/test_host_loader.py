@@ -78,11 +78,9 @@ def test_out_of_scope_features_are_reported_when_used(tmp_path):
     lib_only = json.loads(json.dumps(BASE))
     lib_only["materials"].append({"type": "pndf_conductor", "name": "p", "whatever": 1})
     lib_only["primitives"].append({"type": "catmull_clark", "name": "cc", "ply_file": "x.ply"})
-    lib_only["primitives"].append({"type": "cubic_bezier", "name": "bz"})
     assert load(tmp_path, lib_only).desc.n_instances == 1
     for mutate in (lambda s: s["instances"].append({"name": "j", "primitive": "s", "material": "p"}),
                    lambda s: s["instances"].append({"name": "j", "primitive": "cc", "material": "m"}),
-                   lambda s: s["instances"].append({"name": "j", "primitive": "bz", "material": "m"}),
                    lambda s: s["surfaces"].append({"name": "sf", "material": "p"})):
         bad = json.loads(json.dumps(lib_only))
         mutate(bad)
