@@ -39,6 +39,14 @@ def test_hip_library_exports_its_header_and_has_gfx950_code():
     assert lib.spt_abi_version() == spt.SPT_ABI_VERSION
     blob = open(HIP_SO, "rb").read()
     assert b"gfx950" in blob and b"k_primary" in blob and b"k_shade" in blob
+    # the Bezier-patch build of the same source, opened by libspt_hip.so for scenes with patches: same exports
+    bez = C.CDLL(os.path.join(os.path.dirname(HIP_SO), "libspt_hip_bez.so"))
+    for n in names:
+        assert hasattr(bez, n), n
+    bez.spt_abi_version.restype = C.c_uint32
+    assert bez.spt_abi_version() == spt.SPT_ABI_VERSION
+    blob = open(os.path.join(os.path.dirname(HIP_SO), "libspt_hip_bez.so"), "rb").read()
+    assert b"gfx950" in blob and b"bezier_intersect_ray" in blob
 
 
 @pytest.mark.skipif(not os.path.exists(HIP_SO), reason="libspt_hip.so not built")

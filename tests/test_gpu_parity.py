@@ -421,7 +421,7 @@ def test_full_size_cfg2_properties(spt):
 
 
 @pytest.mark.parametrize("scene_name,camera", [("cfg2_cube.json", None), ("t_materials.json", "main"), ("t_medium.json", None),
-                                               ("t_plastic.json", None), ("t_subsurface.json", None)])
+                                               ("t_plastic.json", None), ("t_subsurface.json", None), ("t_bezier.json", "main")])
 def test_large_scene_path_matches_oracle(spt, scene_name, camera, monkeypatch):
     """The kernels a scene too big for LDS takes (global-memory geometry, compressed 4-wide BLAS nodes with
     conservatively widened child boxes, refilling shadow kernel), forced onto the small test scenes."""
