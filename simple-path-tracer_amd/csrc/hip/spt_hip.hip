@@ -550,6 +550,7 @@ void validate(const spt_scene_desc& s) {
         } else if (in.prim_type == SPT_PRIM_MESH) {
             if (in.prim_id >= s.n_meshes) fail(SPT_ERR_INVALID_ARG, "scene desc: instance mesh index out of range");
         } else if (in.prim_type == SPT_PRIM_BEZIER) {
+            if (!SPT_WITH_BEZIER) fail(SPT_ERR_UNSUPPORTED, "scene desc: Bezier instances are served by libspt_hip_bez.so");   // not reached: spt_scene_create forwards
             if (in.prim_id >= s.n_bezier_patches) fail(SPT_ERR_INVALID_ARG, "scene desc: instance Bezier patch index out of range");
             // CubicBezier::sample / pdf / surface_area are `unimplemented!` in the reference (bezier.rs:180-190)
             if (in.light >= 0) fail(SPT_ERR_UNSUPPORTED, "scene desc: a Bezier patch cannot be a shape light");
@@ -706,7 +707,10 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
     spt_scene* sc = nullptr;
     try {
 #if !SPT_WITH_BEZIER
-        if (desc->n_bezier_patches > 0) {   // see BezierLib
+        bool has_patch_instance = false;   // a patch that no instance uses (a primitives library) does not count
+        if (desc->n_bezier_patches > 0 && desc->instances)
+            for (uint32_t i = 0; i < desc->n_instances && !has_patch_instance; ++i) has_patch_instance = desc->instances[i].prim_type == SPT_PRIM_BEZIER;
+        if (has_patch_instance) {   // see BezierLib
             const BezierLib* lib = bezier_lib();
             spt_scene* inner = nullptr;
             const spt_status st = lib->create(desc, device, &inner);
