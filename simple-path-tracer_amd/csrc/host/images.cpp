@@ -3,7 +3,7 @@
 // reader/writer for `environment {type: "exr"}` (get_exr_image, reference
 // src/core/loader.rs:374-390 reads the first RGBA layer as f32).
 // Supported EXR subset: single-part scanline files, channels R,G,B (A ignored) of
-// type HALF or FLOAT, compression NONE / ZIPS / ZIP, any line order.
+// type HALF or FLOAT, compression NONE / RLE / ZIPS / ZIP / PXR24, any line order.
 #include <zlib.h>
 
 #include <cmath>
@@ -255,11 +255,11 @@ spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height
             }
             r.p = end;
         }
-        if (compression != 0 && compression != 2 && compression != 3)
-            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: only NONE / ZIPS / ZIP compression is supported");
+        if (compression != 0 && compression != 1 && compression != 2 && compression != 3 && compression != 5)
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: only NONE / RLE / ZIPS / ZIP / PXR24 compression is supported (not PIZ, B44, DWA)");
         int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
         if (w <= 0 || h <= 0 || w > 65536 || h > 65536) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad dataWindow");
-        int lines_per_block = (compression == 3) ? 16 : 1;
+        int lines_per_block = (compression == 3 || compression == 5) ? 16 : 1;
         int64_t n_blocks = (h + lines_per_block - 1) / lines_per_block;
         size_t row_bytes = 0;
         std::vector<size_t> chan_off(chans.size());
@@ -293,11 +293,64 @@ spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height
                 if (compression == 0 || (size_t)size == want) {
                     if ((size_t)size != want) throw HostError(SPT_HOST_ERR_PARSE, "exr: chunk size mismatch");
                     std::memcpy(raw.data(), &data[r.p], want);
+                } else if (compression == 5) {
+                    // PXR24 (ImfPxr24Compressor): zlib over byte planes of per-row, per-channel running differences;
+                    // FLOAT samples keep their top 24 bits
+                    size_t packed = 0;
+                    for (const Chan& c : chans) packed += (size_t)w * (c.type == 1 ? 2 : c.type == 2 ? 3 : 4);
+                    packed *= (size_t)lines;
+                    tmp.resize(packed);
+                    uLongf dl = (uLongf)packed;
+                    if (uncompress(tmp.data(), &dl, &data[r.p], (uLong)size) != Z_OK || dl != packed)
+                        throw HostError(SPT_HOST_ERR_PARSE, "exr: zlib inflate failed (PXR24)");
+                    const uint8_t* in = tmp.data();
+                    uint8_t* dst = raw.data();
+                    for (int64_t l = 0; l < lines; ++l)
+                        for (const Chan& c : chans) {
+                            const size_t n = (size_t)w;
+                            if (c.type == 1) {
+                                uint16_t px = 0;
+                                for (size_t x = 0; x < n; ++x) {
+                                    px = (uint16_t)(px + (((uint32_t)in[x] << 8) | in[n + x]));
+                                    std::memcpy(dst + 2 * x, &px, 2);
+                                }
+                                in += 2 * n; dst += 2 * n;
+                            } else {
+                                uint32_t px = 0;
+                                for (size_t x = 0; x < n; ++x) {
+                                    uint32_t diff = ((uint32_t)in[x] << 24) | ((uint32_t)in[n + x] << 16) | ((uint32_t)in[2 * n + x] << 8);
+                                    if (c.type == 0) diff |= in[3 * n + x];
+                                    px += diff;
+                                    std::memcpy(dst + 4 * x, &px, 4);
+                                }
+                                in += (c.type == 0 ? 4 : 3) * n; dst += 4 * n;
+                            }
+                        }
                 } else {
                     tmp.resize(want);
-                    uLongf dl = (uLongf)want;
-                    if (uncompress(tmp.data(), &dl, &data[r.p], (uLong)size) != Z_OK || dl != want)
-                        throw HostError(SPT_HOST_ERR_PARSE, "exr: zlib inflate failed");
+                    if (compression == 1) {
+                        // RLE (ImfRle): a signed count byte, negative = that many literal bytes, else count + 1 copies
+                        size_t ip = r.p, end = r.p + (size_t)size, op = 0;
+                        while (ip < end) {
+                            const int8_t c = (int8_t)data[ip++];
+                            if (c < 0) {
+                                const size_t cnt = (size_t)(-(int)c);
+                                if (ip + cnt > end || op + cnt > want) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad RLE data");
+                                std::memcpy(&tmp[op], &data[ip], cnt);
+                                ip += cnt; op += cnt;
+                            } else {
+                                const size_t cnt = (size_t)c + 1;
+                                if (ip >= end || op + cnt > want) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad RLE data");
+                                std::memset(&tmp[op], data[ip++], cnt);
+                                op += cnt;
+                            }
+                        }
+                        if (op != want) throw HostError(SPT_HOST_ERR_PARSE, "exr: RLE data of the wrong length");
+                    } else {
+                        uLongf dl = (uLongf)want;
+                        if (uncompress(tmp.data(), &dl, &data[r.p], (uLong)size) != Z_OK || dl != want)
+                            throw HostError(SPT_HOST_ERR_PARSE, "exr: zlib inflate failed");
+                    }
                     for (size_t i = 1; i < want; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);
                     size_t half = (want + 1) / 2;
                     for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
