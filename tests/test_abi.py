@@ -85,6 +85,16 @@ def test_invalid_descriptors_are_rejected_before_touching_a_device():
     bad.n_tris = good.n_tris + 5           # BLAS leaves would index past the arrays? no: mesh range check
     bad.tri_pos = None
     assert lib.spt_scene_create(C.byref(bad), 0, C.byref(h)) == 1
+    # a scene with Bezier instances is validated by libspt_hip_bez.so (opened by spt_scene_create): same answers
+    bz = spt.load_scene(os.path.join(_util.SCENES, "t_bezier.json"))
+    bad = spt.SceneDesc.from_buffer_copy(bz.desc)
+    bad.n_bezier_patches = 1               # the instances name patches 0 .. 2
+    assert lib.spt_scene_create(C.byref(bad), 0, C.byref(h)) == 1 and b"Bezier patch index" in lib.spt_last_error()
+    bad = spt.SceneDesc.from_buffer_copy(bz.desc)
+    bad.abi_version = 7
+    assert lib.spt_scene_create(C.byref(bad), 0, C.byref(h)) == 1 and b"abi_version" in lib.spt_last_error()
+    if spt.device_count() == 0:
+        assert lib.spt_scene_create(C.byref(bz.desc), 0, C.byref(h)) == 2 and b"no CPU fallback" in lib.spt_last_error()
     rows = C.c_uint32()
     p = spt.PathTracer(spp=2).params(10, 37, 1, 3, 4)
     assert lib.spt_shard_rows(C.byref(p), C.byref(rows)) == 0
