@@ -321,7 +321,10 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
 // (139 VGPRs for kFeat 0 = 3 waves / SIMD; forcing 128 with a launch bound spills 12 and measured the same.)
 // kTab: the shading tables are read from the LDS-staged blob (tab_ld); always with kFused, and for the un-fused
 // general kernel of any scene whose geometry + tables fit LDS.
-template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused>
+// kGeoLds (kFeat 3 only): the BSSRDF probe walks the LDS-staged traversal geometry.  It has to follow the SCENE
+// (lds_geo), not kTab: a scene whose geometry fits LDS but whose shading tables do not runs the un-tabbed kernel, and
+// its global blob holds the LDS node format, which only the kLds walker reads.
+template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3;
     const uint32_t shard = blockIdx.x % kShards;
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
     // workgroups of an empty shard (most of them in the late bounces) leave before staging anything into LDS;
     // a workgroup whose first item is past the end has nothing to do either (block-uniform, no barrier skipped)
     if ((blockIdx.x / kShards) * blockDim.x >= n) return;
-    if (kFused || kTab) stage_geometry<true>(sc);
+    if (kFused || kTab || kGeoLds) stage_geometry<true>(sc);
     uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
     uint32_t* ext_count = q_count(rc.counts, bounce, Q_EXT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
@@ -540,7 +543,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         ssio.has = false;
                         ssio.po = po;
                         ssio.coord_po = coord;
-                        samp = mat_sample<true, kTab, kTab>(mt, wo, rng, &sc, &ssio);
+                        samp = mat_sample<true, kGeoLds, kTab>(mt, wo, rng, &sc, &ssio);
                         if (ssio.has) {  // pt.rs:147-151
                             po = ssio.pi;
                             coord = ssio.coord_pi;

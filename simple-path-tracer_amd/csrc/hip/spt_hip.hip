@@ -1335,7 +1335,12 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);               \
             else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);                     \
         }
-                    if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) } else { SPT_LAUNCH_SHADE(3) }
+                    if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) }
+                    else if (tab || !L) { SPT_LAUNCH_SHADE(3) }
+                    else {   // geometry in LDS, tables not: the probe still walks the LDS copy (k_shade's kGeoLds)
+                        if (b == 0) hipLaunchKernelGGL((k_shade<3, true, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else hipLaunchKernelGGL((k_shade<3, false, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                    }
 #undef SPT_LAUNCH_SHADE
                     end();
                     // k_shadow(b) and k_extend(b) are independent unless the scene has an environment (then a missing

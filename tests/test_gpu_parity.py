@@ -267,6 +267,21 @@ def test_many_instances_device_tlas(spt, tmp_path):
     assert np.array_equal(film.view(np.uint32)[~nan], ref_film.view(np.uint32)[~nan])
 
 
+@pytest.mark.parametrize("scene_name,camera", [("t_subsurface.json", None), ("t_textured.json", None), ("t_materials.json", "main"), ("t_bezier.json", "low")])
+def test_lds_geometry_without_lds_tables(spt, scene_name, camera, monkeypatch):
+    """A scene whose traversal geometry fits LDS but whose shading tables do not runs the un-tabbed shade kernels; the
+    BSSRDF probe inside k_shade<3> must then still walk the LDS node format (forced here with SPT_NO_LDS_TABLES)."""
+    monkeypatch.setenv("SPT_NO_LDS_TABLES", "1")
+    sc = _scene(spt, scene_name)
+    r = spt.PathTracer(max_depth=6, sampler=spt.SAMPLER_RANDOM, spp=8, seed=17)
+    w, h = 128, 96
+    ref, _ = _util.oracle_render(sc, r, w, h, camera=camera, flags=_util.device_oracle_flags())
+    got = r.render_shard(sc, spt.OutputConfig(w, h, None, camera), samples_per_pass=3)
+    nan = np.isnan(ref)
+    assert np.array_equal(nan, np.isnan(got))
+    assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan])
+
+
 def _same_film(got, ref):
     nan = np.isnan(ref)
     assert np.array_equal(nan, np.isnan(got))
