@@ -282,6 +282,56 @@ def test_lds_geometry_without_lds_tables(spt, scene_name, camera, monkeypatch):
     assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan])
 
 
+def test_mesh_too_large_for_lds_matches_oracle(spt, tmp_path):
+    """A smaller cousin of BASELINE config 5: a 24 k-triangle displaced sphere (deep BLAS: the traversal stack spills
+    past its LDS levels; geometry far beyond LDS, so the global-memory kernels with 4-wide compressed nodes and the
+    refilling walkers run without any switch), inside a box of haze, lit by an emissive quad only."""
+    import importlib.util
+    import json
+    import shutil
+    spec = importlib.util.spec_from_file_location("make_scenes", os.path.join(_util.SCENES, "make_scenes.py"))
+    ms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ms)
+    n = ms.write_displaced_sphere(str(tmp_path / "blob.obj"), 160, 76, 11)
+    assert n == 2 * 160 * 75
+    for name in ("cube.obj", "plane.obj"):
+        shutil.copy(os.path.join(_util.SCENES, "models", name), tmp_path / name)
+    scene = {
+        "cameras": {"type": "perspective", "name": "main", "eye": [0.0, 0.8, 6.0], "forward": [0.0, -0.1, -1.0], "up": [0.0, 1.0, 0.0], "fov": 40.0},
+        "textures": [{"type": "scalar", "name": "white", "value": [0.8, 0.8, 0.8]}, {"type": "scalar", "name": "clay", "value": [0.7, 0.45, 0.3]}],
+        "materials": [{"type": "lambert", "name": "m_floor", "albedo": "white"}, {"type": "lambert", "name": "m_clay", "albedo": "clay"},
+                      {"type": "pseudo", "name": "m_pseudo"}],
+        "mediums": [{"type": "homogeneous", "name": "haze", "sigma_a": [0.05, 0.05, 0.05], "asymmetric": 0.3}],
+        "primitives": [{"type": "trimesh", "name": "blob", "obj_file": "blob.obj"}, {"type": "trimesh", "name": "cube", "obj_file": "cube.obj"},
+                       {"type": "trimesh", "name": "plane", "obj_file": "plane.obj"}],
+        "surfaces": [{"name": "s_haze", "material": "m_pseudo", "inside_medium": "haze"},
+                     {"name": "s_light", "material": "m_floor", "emissive": [10.0, 10.0, 10.0]}],
+        "instances": [{"name": "floor", "primitive": "plane", "material": "m_floor", "scale": [8.0, 1.0, 8.0], "translate": [0.0, -1.5, 0.0]},
+                      {"name": "blob", "primitive": "blob", "material": "m_clay"},
+                      {"name": "hazebox", "primitive": "cube", "surface": "s_haze", "scale": [2.0, 2.0, 2.0]},
+                      {"name": "quad", "primitive": "plane", "surface": "s_light", "scale": [1.5, 1.0, 1.5], "rotate": [180.0, 0.0, 0.0], "translate": [0.0, 3.5, 0.0]}],
+        "lights": [],
+    }
+    (tmp_path / "blob.json").write_text(json.dumps(scene))
+    sc = spt.load_scene(str(tmp_path / "blob.json"))
+    assert sc.desc.n_tris == n + 12 + 2
+    rays = _util.random_rays(sc, 30_000, seed=4)
+    ref = _util.oracle_trace_closest(sc, rays, _util.device_oracle_flags())
+    got = sc.device_scene(0).trace_closest(rays)
+    assert (ref["instance"] >= 0).mean() > 0.3
+    if not os.environ.get("SPT_REFERENCE_BVH"):
+        assert ref.tobytes() == got.tobytes()
+    else:
+        assert (ref["t"].view(np.uint32) == got["t"].view(np.uint32)).mean() > 0.999
+    r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RECURRENCE, spp=4, seed=6)
+    w, h = 128, 96
+    ref_film, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags())
+    film = r.render_shard(sc, spt.OutputConfig(w, h))
+    assert ref_film.max() > 0.05 and not np.isnan(ref_film).any()
+    mism = int((film.view(np.uint32) != ref_film.view(np.uint32)).sum())
+    assert mism == 0, mism
+
+
 def _same_film(got, ref):
     nan = np.isnan(ref)
     assert np.array_equal(nan, np.isnan(got))
