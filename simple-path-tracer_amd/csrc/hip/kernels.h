@@ -575,6 +575,17 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                             }
                         }
                     }
+                    if (kSubsurface && !all_finite(thr) && !mat_is_delta(mt)) {
+                        // Only the BSSRDF relocation above can leave a non-finite throughput in front of the light
+                        // sample (sp / pdf_pi = 0 / 0 where the profile underflows).  The reference then adds
+                        // throughput * li with li = 0 for an occluded or rejected light sample (pt.rs:163-181), which
+                        // is NaN, not "nothing": the one place where skipping a zero contribution is not the same
+                        // thing.  Resolved right here (k_shade<3> can trace), the shadow queue never sees it.
+                        f3 add = thr * 0.0f;
+                        if (want_shadow && !trace_any<kGeoLds>(sc, shadow_ray, shadow_tmax)) add = contrib;
+                        rad_add(rc, slot, add);
+                        want_shadow = false;
+                    }
                     next_pdf = samp.pdf;
                     f3 wi_world = coord.to_world(samp.wi);
                     next_ray.o = po; next_ray.d = wi_world;

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Random scenes, GPU against oracle, bit for bit.
+
+Every seed draws a scene from the whole supported schema - all material kinds (constant and image-textured
+parameters), texture graphs, normal / emissive maps, media, spheres / meshes / Bezier patches with random transforms,
+every light type, colour / EXR / no environment, both aggregates and light samplers - and a renderer configuration
+(sampler, spp, depth, box-filter radius, samples per pass, shard layout), renders it through the C ABI and through
+the oracle and compares the films word by word (NaN positions must agree).  A developer tool, not a test:
+
+    gpurun -- python tools/fuzz_scenes.py --seeds 0:40          (GPU box; exit code 1 and the seed on any mismatch)
+
+The scene JSON of a failing seed is left in gpurun_out/fuzz/; `--seeds N:N+1` reproduces it.  tests/test_gpu_fuzz.py
+runs a fixed handful of seeds (including every seed that ever failed) with the GPU suite."""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _util  # noqa: E402
+
+spt = _util.load_pkg()
+SCENES = os.path.join(ROOT, "scenes_amd")
+
+
+def f3(rng, lo, hi):
+    return [float(x) for x in rng.uniform(lo, hi, 3)]
+
+
+def make_scene(rng):
+    tex = [{"type": "scalar", "name": "c%d" % k, "value": f3(rng, 0.05, 0.95)} for k in range(4)]
+    tex += [{"type": "scalar", "name": "r%d" % k, "value": [float(v)] * 3} for k, v in enumerate((0.0, 0.12, 0.3, 0.55))]
+    tex += [{"type": "scalar", "name": "eta", "value": f3(rng, 0.1, 1.6)}, {"type": "scalar", "name": "kk", "value": f3(rng, 1.5, 4.0)},
+            {"type": "scalar", "name": "one", "value": [1.0, 1.0, 1.0]}, {"type": "scalar", "name": "ld", "value": f3(rng, 0.2, 0.8)}]
+    images = ["checker.png", "noise_rgba.png", "rough_ramp.png", "stripes_ga.png"]
+    wraps = ["repeat", "clamp", "mirror_repeat", "mirror_clamp"]
+    img_names = []
+    for k in range(int(rng.integers(0, 4))):
+        t = {"type": "image", "name": "img%d" % k, "image_file": "textures/" + images[int(rng.integers(0, len(images)))]}
+        if rng.random() < 0.6:
+            t["tiling"] = [float(rng.uniform(0.5, 5.0)), float(rng.uniform(0.5, 5.0))]
+        if rng.random() < 0.3:
+            t["offset"] = [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))]
+        if rng.random() < 0.5:
+            t["wrap"] = wraps[int(rng.integers(0, 4))]
+        if rng.random() < 0.3:
+            t["is_srgb"] = True
+        if rng.random() < 0.15:
+            t["mode"] = ["position", "normal"][int(rng.integers(0, 2))]
+            t["tiling"] = f3(rng, 0.3, 1.5)
+            t.pop("offset", None)
+        tex.append(t)
+        img_names.append(t["name"])
+    if img_names and rng.random() < 0.5:
+        tex.append({"type": ["mul", "add", "sub"][int(rng.integers(0, 3))], "name": "op0", "t1": img_names[0], "t2": "c0"})
+        img_names.append("op0")
+    normal_map = None
+    if rng.random() < 0.3:
+        tex.append({"type": "image", "name": "bumps", "image_file": "textures/bumps_normal.png", "tiling": [float(rng.uniform(1, 5))] * 2})
+        normal_map = "bumps"
+
+    def colour():
+        return img_names[int(rng.integers(0, len(img_names)))] if img_names and rng.random() < 0.4 else "c%d" % int(rng.integers(0, 4))
+
+    def rough():
+        if img_names and rng.random() < 0.2:
+            return "img0" if "img0" in img_names else "r2"
+        return "r%d" % int(rng.integers(0, 4))
+
+    def roughness_fields(m):
+        if rng.random() < 0.3:
+            m["roughness_x"], m["roughness_y"] = rough(), rough()
+        else:
+            m["roughness"] = rough()
+        return m
+
+    mats = []
+    kinds = ["lambert", "conductor", "dielectric", "plastic", "pbr_metallic", "pbr_specular", "subsurface", "lambert", "conductor"]
+    for k in range(int(rng.integers(2, 7))):
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        m = {"type": kind, "name": "m%d" % k}
+        if kind == "lambert":
+            m["albedo"] = colour()
+        elif kind == "conductor":
+            m.update(ior="eta", ior_k="kk")
+            roughness_fields(m)
+        elif kind == "dielectric":
+            m.update(int_ior=float(rng.uniform(1.2, 1.8)), reflectance="one", transmittance=colour() if rng.random() < 0.3 else "one")
+            if rng.random() < 0.5:
+                m["ext_ior"] = 1.0
+            roughness_fields(m)
+        elif kind == "plastic":
+            m.update(int_ior=float(rng.uniform(1.3, 1.7)), albedo=colour())
+            roughness_fields(m)
+        elif kind == "pbr_metallic":
+            m.update(base_color=colour(), metallic="c%d" % int(rng.integers(0, 4)))
+            roughness_fields(m)
+        elif kind == "pbr_specular":
+            m.update(diffuse=colour(), specular="c%d" % int(rng.integers(0, 4)))
+            roughness_fields(m)
+        else:
+            m.update(int_ior=float(rng.uniform(1.3, 1.6)), albedo=colour(), ld="ld")
+            roughness_fields(m)
+        mats.append(m)
+    mats.append({"type": "pseudo", "name": "pseudo"})
+    mediums = []
+    for k in range(int(rng.integers(0, 3))):
+        md = {"type": "homogeneous", "name": "med%d" % k, "sigma_a": f3(rng, 0.02, 0.8), "asymmetric": float(rng.choice([0.0, 0.3, -0.4, 0.005]))}
+        if rng.random() < 0.5:
+            md["sigma_s"] = f3(rng, 0.1, 4.0)      # read but unused by the reference (quirk Q4): must not matter
+        mediums.append(md)
+    prims = [{"type": "sphere", "name": "ball", "radius": 1.0},
+             {"type": "sphere", "name": "off_ball", "center": f3(rng, -0.3, 0.3), "radius": float(rng.uniform(0.3, 0.8))},
+             {"type": "trimesh", "name": "cube", "obj_file": "models/cube.obj"},
+             {"type": "trimesh", "name": "plane", "obj_file": "models/plane.obj"},
+             {"type": "trimesh", "name": "blob", "obj_file": "models/blob_small.obj"}]
+    use_patches = rng.random() < 0.35
+    if use_patches:
+        h = rng.uniform(-0.5, 1.2, (4, 4))
+        prims.append({"type": "cubic_bezier", "name": "patch",
+                      "control_points": [[[float(-1.5 + j + rng.uniform(-0.2, 0.2)), float(h[i][j]), float(1.5 - i + rng.uniform(-0.2, 0.2))] for j in range(4)] for i in range(4)]})
+    surfaces = []
+    for k in range(int(rng.integers(0, 4))):
+        s = {"name": "s%d" % k, "material": mats[int(rng.integers(0, len(mats)))]["name"]}
+        roll = rng.random()
+        if roll < 0.45:
+            s["emissive"] = f3(rng, 1.0, 12.0)
+            if img_names and rng.random() < 0.3:
+                s["emissive_map"] = img_names[0]
+        elif roll < 0.75 and mediums:
+            s["material"] = "pseudo" if rng.random() < 0.7 else s["material"]
+            s["inside_medium"] = mediums[int(rng.integers(0, len(mediums)))]["name"]
+        if rng.random() < 0.3:
+            s["double_sided"] = True
+        if normal_map and rng.random() < 0.5:
+            s["normal_map"] = normal_map
+        surfaces.append(s)
+    inst = [{"name": "floor", "primitive": "plane", "material": mats[0]["name"], "scale": [6.0, 1.0, 6.0], "translate": [0.0, -1.2, 0.0]}]
+    names = ["ball", "off_ball", "cube", "plane", "blob"] + (["patch", "patch"] if use_patches else [])
+    for k in range(int(rng.integers(2, 9))):
+        prim = names[int(rng.integers(0, len(names)))]
+        i = {"name": "i%d" % k, "primitive": prim}
+        s = None
+        if surfaces and rng.random() < 0.5:
+            s = surfaces[int(rng.integers(0, len(surfaces)))]
+            if prim == "patch" and "emissive" in s:
+                s = None                                    # CubicBezier cannot be a shape light (bezier.rs:188-190)
+        if s is not None:
+            i["surface"] = s["name"]
+        else:
+            i["material"] = mats[int(rng.integers(0, len(mats) - 1))]["name"]
+        sc = float(rng.uniform(0.3, 1.1))
+        i["scale"] = [sc, sc * float(rng.uniform(0.6, 1.5)), sc] if rng.random() < 0.5 else [sc, sc, sc]
+        if rng.random() < 0.6:
+            i["rotate"] = f3(rng, -180.0, 180.0)
+        i["translate"] = [float(rng.uniform(-2.5, 2.5)), float(rng.uniform(-0.8, 1.8)), float(rng.uniform(-2.0, 2.0))]
+        inst.append(i)
+    lights = []
+    for k in range(int(rng.integers(0, 4))):
+        kind = ["directional", "point", "spot"][int(rng.integers(0, 3))]
+        li = {"type": kind, "name": "l%d" % k, "strength": f3(rng, 1.0, 15.0)}
+        if kind != "point":
+            li["direction"] = [float(rng.uniform(-1, 1)), float(rng.uniform(-1.0, -0.2)), float(rng.uniform(-1, 1))]
+        if kind != "directional":
+            li["position"] = [float(rng.uniform(-3, 3)), float(rng.uniform(1.5, 4)), float(rng.uniform(-3, 3))]
+        if kind == "spot":
+            li["inner_angle"], li["outer_angle"] = float(rng.uniform(5, 25)), float(rng.uniform(26, 60))
+        lights.append(li)
+    eye = np.array([rng.uniform(-3, 3), rng.uniform(0.5, 4.0), rng.uniform(4.0, 7.0)])
+    fwd = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.6, 0.4), 0.0]) - eye
+    scene = {"cameras": {"type": "perspective", "name": "cam", "eye": [float(x) for x in eye], "forward": [float(x) for x in fwd], "up": [0.0, 1.0, 0.0],
+                         "fov": float(rng.uniform(30, 70))},
+             "textures": tex, "materials": mats, "mediums": mediums, "primitives": prims, "surfaces": surfaces, "instances": inst, "lights": lights}
+    env = rng.random()
+    if env < 0.35:
+        scene["environment"] = {"type": "color", "color": f3(rng, 0.05, 0.6)}
+    elif env < 0.55:
+        scene["environment"] = {"type": "exr", "exr_file": "textures/env_small.exr", "scale": f3(rng, 0.3, 1.0)}
+    if rng.random() < 0.3:
+        scene["aggregate"] = "group"
+    if rng.random() < 0.4:
+        scene["light_sampler"] = "power_is"
+    return scene
+
+
+def stage_assets():
+    work = tempfile.mkdtemp(prefix="spt_fuzz_")
+    for sub in ("models", "textures"):
+        shutil.copytree(os.path.join(SCENES, sub), os.path.join(work, sub))
+    return work
+
+
+def run_seed(seed, work):
+    """-> (ok or None when the loader rejected the scene, one-line description, path of the scene JSON)"""
+    rng = np.random.default_rng(1000 + seed)
+    scene = make_scene(rng)
+    path = os.path.join(work, "fuzz_%d.json" % seed)
+    with open(path, "w") as fh:
+        json.dump(scene, fh, indent=1)
+    sampler = int(rng.integers(0, 3))
+    dx, dy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    spp = dx * dy if sampler == spt.SAMPLER_JITTERED else int(rng.integers(1, 9))
+    radius = float(rng.choice([0.5, 0.5, 0.5, 0.3, 1.2, 1.6]))
+    r = spt.PathTracer(max_depth=int(rng.integers(1, 9)), sampler=sampler, spp=spp, division_x=dx, division_y=dy, seed=int(rng.integers(0, 1 << 30)), filter_radius=radius)
+    w, h = int(rng.integers(17, 120)), int(rng.integers(9, 90))
+    shard_count = int(rng.choice([1, 1, 2, 3]))
+    strip_rows = int(rng.choice([1, 4, 16]))
+    spp_pass = int(rng.integers(0, spp + 1))
+    try:
+        sc = spt.load_scene(path)
+    except spt.SptError as e:
+        return None, "scene rejected by the loader: %s" % str(e)[:120], path
+    ok, words, nan_px = True, 0, 0
+    for k in range(shard_count):
+        ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags(), shard_index=k, shard_count=shard_count, strip_rows=strip_rows)
+        got = r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=shard_count, strip_rows=strip_rows, samples_per_pass=spp_pass)
+        nan = np.isnan(ref)
+        same_nan = np.array_equal(nan, np.isnan(got))
+        diff = int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum())
+        ok = ok and same_nan and diff == 0
+        words += diff
+        nan_px += int(nan.any(axis=2).sum())
+    kinds = sorted({m["type"] for m in scene["materials"]})
+    info = ("%s  %dx%d spp %d depth %d sampler %d radius %.1f shards %d/%d pass %d  inst %d lights %d env %s patches %d media %d  NaN px %d  words differ %d  %s" %
+            ("ok  " if ok else "FAIL", w, h, spp, r.max_depth, sampler, radius, shard_count, strip_rows, spp_pass, len(scene["instances"]), len(scene["lights"]),
+             scene.get("environment", {}).get("type", "-"), sc.desc.n_bezier_patches, len(scene["mediums"]), nan_px, words, ",".join(k[:4] for k in kinds)))
+    sc.close()
+    return ok, info, path
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0:20")
+    args = ap.parse_args()
+    lo, hi = (int(x) for x in args.seeds.split(":"))
+    out_dir = os.path.join(ROOT, "gpurun_out", "fuzz")
+    work = stage_assets()
+    bad = 0
+    for seed in range(lo, hi):
+        ok, info, path = run_seed(seed, work)
+        print("seed %4d: %s" % (seed, info), flush=True)
+        if ok is False:
+            bad += 1
+            os.makedirs(out_dir, exist_ok=True)
+            shutil.copy(path, os.path.join(out_dir, os.path.basename(path)))
+    shutil.rmtree(work, ignore_errors=True)
+    print("%d of %d seeds failed" % (bad, hi - lo))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
