@@ -92,13 +92,12 @@ int decode_sym(BitReader& br, const Huff& h, const std::string& label) {
     uint32_t look = br.peek(16);
     int len = h.look_len[look >> 8];
     if (len) { br.skip(len); return h.look_val[look >> 8]; }
-    int32_t code = (int32_t)(look >> 7);   // 9 bits
     for (len = 9; len <= 16; ++len) {
+        const int32_t code = (int32_t)(look >> (16 - len));   // the first `len` bits
         if (code <= h.maxcode[len]) {
             br.skip(len);
             return h.vals[(h.valptr[len] + code - h.mincode[len]) & 255];
         }
-        code = (int32_t)(look >> (15 - len));
     }
     throw HostError(SPT_HOST_ERR_PARSE, "jpeg '" + label + "': bad Huffman code");
 }
@@ -115,28 +114,28 @@ struct Comp {
 // jidctint.c (IJG "islow"): 13-bit constants, 2 extra bits between the passes
 void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) {
     constexpr int CB = 13, P1 = 2;
-    constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
+    constexpr int64_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
                       F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-    auto descale = [](int32_t x, int n) { return (x + (1 << (n - 1))) >> n; };
-    int32_t ws[64];
+    auto descale = [](int64_t x, int n) { return (x + ((int64_t)1 << (n - 1))) >> n; };   // 64-bit: a corrupt file cannot overflow it, a valid one gives the 32-bit values
+    int64_t ws[64];
     for (int c = 0; c < 8; ++c) {
         const int16_t* ip = in + c;
         const uint16_t* qp = q + c;
-        int32_t* wp = ws + c;
+        int64_t* wp = ws + c;
         if (!ip[8] && !ip[16] && !ip[24] && !ip[32] && !ip[40] && !ip[48] && !ip[56]) {
-            int32_t dc = (int32_t)ip[0] * qp[0] * (1 << P1);
+            int64_t dc = (int64_t)ip[0] * qp[0] * (1 << P1);
             for (int r = 0; r < 8; ++r) wp[8 * r] = dc;
             continue;
         }
-        int32_t z2 = ip[16] * qp[16], z3 = ip[48] * qp[48];
-        int32_t z1 = (z2 + z3) * F0_541;
-        int32_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-        z2 = ip[0] * qp[0]; z3 = ip[32] * qp[32];
-        int32_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
-        int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        tmp0 = ip[56] * qp[56]; tmp1 = ip[40] * qp[40]; tmp2 = ip[24] * qp[24]; tmp3 = ip[8] * qp[8];
+        int64_t z2 = (int64_t)ip[16] * qp[16], z3 = (int64_t)ip[48] * qp[48];
+        int64_t z1 = (z2 + z3) * F0_541;
+        int64_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+        z2 = (int64_t)ip[0] * qp[0]; z3 = (int64_t)ip[32] * qp[32];
+        int64_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
+        int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = (int64_t)ip[56] * qp[56]; tmp1 = (int64_t)ip[40] * qp[40]; tmp2 = (int64_t)ip[24] * qp[24]; tmp3 = (int64_t)ip[8] * qp[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * F1_175;
+        int64_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * F1_175;
         tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
         z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
         z3 += z5; z4 += z5;
@@ -146,18 +145,18 @@ void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) 
         wp[16] = descale(tmp12 + tmp1, CB - P1); wp[40] = descale(tmp12 - tmp1, CB - P1);
         wp[24] = descale(tmp13 + tmp0, CB - P1); wp[32] = descale(tmp13 - tmp0, CB - P1);
     }
-    auto clamp8 = [](int32_t x) { x += 128; return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); };
+    auto clamp8 = [](int64_t x) { x += 128; return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); };
     for (int r = 0; r < 8; ++r) {
-        const int32_t* wp = ws + 8 * r;
+        const int64_t* wp = ws + 8 * r;
         uint8_t* op = out + (size_t)r * stride;
-        int32_t z2 = wp[2], z3 = wp[6];
-        int32_t z1 = (z2 + z3) * F0_541;
-        int32_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-        int32_t tmp0 = (wp[0] + wp[4]) * (1 << CB), tmp1 = (wp[0] - wp[4]) * (1 << CB);
-        int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int64_t z2 = wp[2], z3 = wp[6];
+        int64_t z1 = (z2 + z3) * F0_541;
+        int64_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+        int64_t tmp0 = (wp[0] + wp[4]) * (1 << CB), tmp1 = (wp[0] - wp[4]) * (1 << CB);
+        int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = wp[7]; tmp1 = wp[5]; tmp2 = wp[3]; tmp3 = wp[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * F1_175;
+        int64_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * F1_175;
         tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
         z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
         z3 += z5; z4 += z5;
@@ -273,7 +272,7 @@ struct Decoder {
             if (!progressive) {
                 const int t = decode_sym(br, dc[k.td], label);
                 if (t > 15) bad("bad DC category");
-                k.pred += t ? extend(br.get(t), t) : 0;
+                k.pred = (int32_t)((uint32_t)k.pred + (uint32_t)(t ? extend(br.get(t), t) : 0));   // wraps on corrupt data instead of overflowing
                 blk[0] = (int16_t)k.pred;
                 const Huff& h = ac[k.ta];
                 for (int i = 1; i < 64;) {
@@ -290,8 +289,8 @@ struct Decoder {
                 if (Ah == 0) {
                     const int t = decode_sym(br, dc[k.td], label);
                     if (t > 15) bad("bad DC category");
-                    k.pred += t ? extend(br.get(t), t) : 0;
-                    blk[0] = (int16_t)(k.pred * (1 << Al));
+                    k.pred = (int32_t)((uint32_t)k.pred + (uint32_t)(t ? extend(br.get(t), t) : 0));
+                    blk[0] = (int16_t)((uint32_t)k.pred << Al);
                 } else if (br.bit()) {
                     blk[0] = (int16_t)(blk[0] | (1 << Al));
                 }
@@ -305,7 +304,7 @@ struct Decoder {
                     if (s) {
                         i += r;
                         if (i > 63) bad("AC run past the block");
-                        blk[kZigzag[i]] = (int16_t)(extend(br.get(s), s) * (1 << Al));
+                        blk[kZigzag[i]] = (int16_t)((uint32_t)extend(br.get(s), s) << Al);
                         ++i;
                     } else if (r == 15) {
                         i += 16;
