@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mutation fuzzing of everything the host library parses: PNG / JPEG / EXR decoders (byte flips, insertions, cuts of
-valid files) and the scene loader (structural mutations of scene JSON: dropped keys, wrong types, wrong lengths,
-huge / tiny numbers; byte mutations of the JSON text).  Every input must either load or raise SptError - never crash,
+valid files), the scene loader (structural mutations of scene JSON: dropped keys, wrong types, wrong lengths,
+huge / tiny numbers; byte mutations of the JSON text), glTF documents with their binary buffers and OBJ files.  Every input must either load or raise SptError - never crash,
 never trip a sanitizer.  Meant to run against an ASan + UBSan build of libspt_host.so in a COPY of the repo:
 
     cp -r include oracle scenes_amd simple-path-tracer_amd tests tools Makefile /tmp/fz/ && cd /tmp/fz
@@ -10,7 +10,7 @@ never trip a sanitizer.  Meant to run against an ASan + UBSan build of libspt_ho
     ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
     LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" python tools/fuzz_host_inputs.py SEED COUNT
 
-Round 1: 5 seeds x 2 000 inputs clean after two findings in the JPEG decoder (a shift by -1 after the last Huffman
+Round 1: 8 seeds x 2 000 - 2 400 inputs clean after two findings in the JPEG decoder (a shift by -1 after the last Huffman
 length, 32-bit overflow in the IDCT on corrupt coefficients)."""
 import sys, os, io, json, random, shutil, tempfile, ctypes as C
 import numpy as np
@@ -80,4 +80,20 @@ for it in range(N):
     # raw text mutations of the JSON too
     txt = mutate(json.dumps(rnd.choice([base, base2])).encode())
     open(p, "wb").write(txt); attempt(spt.load_scene, p)
+# glTF (JSON + binary buffer) and OBJ
+gltf = json.load(open(os.path.join(ROOT, "scenes_amd", "t_gltf.gltf")))
+gbin = open(os.path.join(ROOT, "scenes_amd", "models", "t_gltf.bin"), "rb").read()
+obj = open(os.path.join(ROOT, "scenes_amd", "models", "cube.obj"), "rb").read()
+obj_scene = {"cameras": {"type": "perspective", "name": "c", "eye": [0.0, 0.0, 4.0], "forward": [0.0, 0.0, -1.0], "up": [0.0, 1.0, 0.0], "fov": 40.0},
+             "textures": [{"type": "scalar", "name": "w", "value": [0.5, 0.5, 0.5]}], "materials": [{"type": "lambert", "name": "m", "albedo": "w"}],
+             "mediums": [], "surfaces": [], "primitives": [{"type": "trimesh", "name": "o", "obj_file": "models/fz.obj"}],
+             "instances": [{"name": "i", "primitive": "o", "material": "m"}], "lights": []}
+json.dump(obj_scene, open(os.path.join(work, "obj.json"), "w"))
+for it in range(N):
+    g = mut_json(gltf)
+    json.dump(g, open(os.path.join(work, "g.gltf"), "w"))
+    open(os.path.join(work, "models", "t_gltf.bin"), "wb").write(gbin if rnd.random() < 0.5 else mutate(gbin))
+    attempt(spt.load_scene, os.path.join(work, "g.gltf"))
+    open(os.path.join(work, "models", "fz.obj"), "wb").write(mutate(obj))
+    attempt(spt.load_scene, os.path.join(work, "obj.json"))
 print(stats)
