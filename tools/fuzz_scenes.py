@@ -208,6 +208,13 @@ def run_seed(seed, work):
     radius = float(rng.choice([0.5, 0.5, 0.5, 0.3, 1.2, 1.6]))
     r = spt.PathTracer(max_depth=int(rng.integers(1, 9)), sampler=sampler, spp=spp, division_x=dx, division_y=dy, seed=int(rng.integers(0, 1 << 30)), filter_radius=radius)
     w, h = int(rng.integers(17, 120)), int(rng.integers(9, 90))
+    # FUZZ_SIZE_MUL / FUZZ_SPP_MUL: the same scenes at larger images / sample counts (several wavefront passes, sample
+    # chunks, full queues); the exhaustive oracle then takes seconds per seed
+    size_mul, spp_mul = int(os.environ.get("FUZZ_SIZE_MUL", "1")), int(os.environ.get("FUZZ_SPP_MUL", "1"))
+    w, h = w * size_mul, h * size_mul
+    if sampler != spt.SAMPLER_JITTERED and spp_mul > 1:
+        spp *= spp_mul
+        r.spp = spp
     shard_count = int(rng.choice([1, 1, 2, 3]))
     strip_rows = int(rng.choice([1, 4, 16]))
     spp_pass = int(rng.integers(0, spp + 1))
