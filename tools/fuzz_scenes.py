@@ -220,6 +220,16 @@ def run_seed(seed, work):
     shard_count = int(rng.choice([1, 1, 2, 3]))
     strip_rows = int(rng.choice([1, 4, 16]))
     spp_pass = int(rng.integers(0, spp + 1))
+    # FUZZ_SWITCHES=1: a random subset of the library's A/B switches per seed (read at scene creation / render time)
+    switches = {}
+    if os.environ.get("FUZZ_SWITCHES"):
+        for name, values in (("SPT_NO_FUSED", ["1"]), ("SPT_NO_LDS_TABLES", ["1"]), ("SPT_NO_LDS_GEO", ["1"]), ("SPT_NO_PIXEL_CULL", ["1"]),
+                             ("SPT_NO_OVERLAP", ["1"]), ("SPT_NO_DYN_SHADOW", ["1"]), ("SPT_NO_DYN_EXTEND", ["1"]), ("SPT_PRIMARY_CHUNKS", ["1", "2", "7"]),
+                             ("SPT_BOX_BAND_BYTES", ["20000", "300000"]), ("SPT_BVH_MAX_LEAF", ["1", "2", "8"]), ("SPT_DYN_BLOCKS", ["64", "512"])):
+            os.environ.pop(name, None)
+            if rng.random() < 0.25:
+                switches[name] = values[int(rng.integers(0, len(values)))]
+        os.environ.update(switches)
     try:
         sc = spt.load_scene(path)
     except spt.SptError as e:
@@ -264,6 +274,8 @@ def run_seed(seed, work):
     info = ("%s  rays %s  %dx%d spp %d depth %d sampler %d radius %.1f shards %d/%d pass %d  inst %d lights %d env %s patches %d media %d  NaN px %d  words differ %d  %s" %
             ("ok  " if ok else "FAIL", "ok" if ray_bad == 0 else "BAD(%d)" % ray_bad, w, h, spp, r.max_depth, sampler, radius, shard_count, strip_rows, spp_pass, len(scene["instances"]), len(scene["lights"]),
              scene.get("environment", {}).get("type", "-"), sc.desc.n_bezier_patches, len(scene["mediums"]), nan_px, words, ",".join(k[:4] for k in kinds)))
+    if switches:
+        info += "  " + " ".join("%s=%s" % kv for kv in sorted(switches.items()))
     sc.close()
     return ok, info, path
 
