@@ -85,7 +85,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--backend", default="cpu:gloo,cuda:nccl", help="torch.distributed backend (N > 1)")
+    ap.add_argument("--backend", default="gloo",
+                    help="torch.distributed backend of the control plane (N > 1): a barrier, one max-reduce of a double and one "
+                         "name broadcast.  The data path has no collective (every rank writes its rows into the shared film), so "
+                         "nothing needs RCCL; pass cpu:gloo,cuda:nccl to run the barriers over RCCL / xGMI instead")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -106,7 +109,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."); stdout carries exactly one JSON
+        # line, so file descriptor 1 points at stderr while the process group comes up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+            dist.barrier(device_ids=[local_rank]) if "nccl" in args.backend else dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     spt = load_pkg()
     scene = spt.load_scene(args.scene)
@@ -118,11 +132,12 @@ def main():
     scene.device_scene(local_rank)
 
     def barrier():
+        torch.cuda.synchronize()          # this rank's GPU work is done ...
         if dist is not None:
             if "nccl" in args.backend:
                 dist.barrier(device_ids=[local_rank])
             else:
-                dist.barrier()
+                dist.barrier()            # ... and so is everybody else's
         torch.cuda.synchronize()
 
     film = None
