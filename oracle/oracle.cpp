@@ -6,11 +6,12 @@
 //
 // What it restates (reference = /root/reference, PepcyCh/simple-path-tracer, Rust):
 //   src/renderer/pt.rs            trace_ray, shadow_ray_from_medium, render, power_heuristic
-//   src/primitive/{bvh,group,instance,triangle,sphere}.rs   intersect / intersect_test / sample / pdf
+//   src/primitive/{bvh,group,instance,triangle,sphere,bezier}.rs   intersect / intersect_test / sample / pdf
 //   src/core/{ray,bbox,intersection,coord,transform,color,film}.rs
 //   src/core/surface.rs, src/material/*.rs (resolved on the host for scalar textures)
 //   src/bxdf/{lambert,util,fresnel,microfacet,microfacet_conductor,microfacet_dielectric,
-//             specular_conductor,specular_dielectric,pseudo}.rs
+//             specular_conductor,specular_dielectric,pseudo,microfacet_plastic,specular_plastic,substrate}.rs
+//   src/texture/*.rs, src/core/intersection.rs (ray differentials), src/filter/boxf.rs
 //   src/light_sampler/{uniform,power_is}.rs, src/core/alias_table.rs, src/light/*.rs
 //   src/medium/{homogeneous,util}.rs, src/camera/perspective.rs, src/pixel_sampler/*.rs
 // Each function cites the lines it follows.  Scalar f32, one expression per
