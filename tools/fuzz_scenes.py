@@ -53,7 +53,7 @@ def make_scene(rng):
         if rng.random() < 0.3:
             t["is_srgb"] = True
         if rng.random() < 0.15:
-            t["mode"] = ["position", "normal"][int(rng.integers(0, 2))]
+            t["mode"] = ["position", "normal", "tangent", "bitangent"][int(rng.integers(0, 4 if os.environ.get("FUZZ_V2") else 2))]
             t["tiling"] = f3(rng, 0.3, 1.5)
             t.pop("offset", None)
         tex.append(t)
@@ -61,6 +61,9 @@ def make_scene(rng):
     if img_names and rng.random() < 0.5:
         tex.append({"type": ["mul", "add", "sub"][int(rng.integers(0, 3))], "name": "op0", "t1": img_names[0], "t2": "c0"})
         img_names.append("op0")
+        if os.environ.get("FUZZ_V2") and rng.random() < 0.5:     # a second level: (img op c0) / one, sRGB-decoded
+            tex.append({"type": "div", "name": "op1", "t1": "op0", "t2": "one", "is_srgb": bool(rng.random() < 0.5)})
+            img_names.append("op1")
     normal_map = None
     if rng.random() < 0.3:
         tex.append({"type": "image", "name": "bumps", "image_file": "textures/bumps_normal.png", "tiling": [float(rng.uniform(1, 5))] * 2})
@@ -98,6 +101,8 @@ def make_scene(rng):
             roughness_fields(m)
         elif kind == "plastic":
             m.update(int_ior=float(rng.uniform(1.3, 1.7)), albedo=colour())
+            if os.environ.get("FUZZ_V2") and rng.random() < 0.4:
+                m["ext_ior"] = float(rng.uniform(1.0, 1.2))
             roughness_fields(m)
         elif kind == "pbr_metallic":
             m.update(base_color=colour(), metallic="c%d" % int(rng.integers(0, 4)))
