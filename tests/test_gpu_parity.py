@@ -332,6 +332,44 @@ def test_mesh_too_large_for_lds_matches_oracle(spt, tmp_path):
     assert mism == 0, mism
 
 
+def test_mid_size_mesh_lds_geometry_but_global_tables(spt, tmp_path):
+    """288 triangles: the traversal blob (positions, nodes) fits LDS, the shading tables (144 B of attributes per triangle)
+    do not - the configuration SPT_NO_LDS_TABLES forces on the small scenes, here reached by the scene itself; with a
+    Subsurface material so that the BSSRDF probe walks the LDS geometry from the un-tabbed kernel."""
+    import importlib.util
+    import json
+    import shutil
+    spec = importlib.util.spec_from_file_location("make_scenes", os.path.join(_util.SCENES, "make_scenes.py"))
+    ms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ms)
+    assert ms.write_displaced_sphere(str(tmp_path / "blob.obj"), 24, 7, 5) == 288
+    shutil.copy(os.path.join(_util.SCENES, "models", "plane.obj"), tmp_path / "plane.obj")
+    scene = {
+        "cameras": {"type": "perspective", "name": "main", "eye": [0.0, 1.0, 5.0], "forward": [0.0, -0.15, -1.0], "up": [0.0, 1.0, 0.0], "fov": 40.0},
+        "textures": [{"type": "scalar", "name": "white", "value": [0.8, 0.8, 0.8]}, {"type": "scalar", "name": "skin", "value": [0.8, 0.55, 0.45]},
+                     {"type": "scalar", "name": "ld", "value": [0.5, 0.5, 0.5]}, {"type": "scalar", "name": "r", "value": [0.3, 0.3, 0.3]}],
+        "materials": [{"type": "lambert", "name": "m_floor", "albedo": "white"},
+                      {"type": "subsurface", "name": "m_ss", "int_ior": 1.4, "albedo": "skin", "ld": "ld", "roughness": "r"}],
+        "mediums": [],
+        "primitives": [{"type": "trimesh", "name": "blob", "obj_file": "blob.obj"}, {"type": "trimesh", "name": "plane", "obj_file": "plane.obj"}],
+        "surfaces": [{"name": "s_light", "material": "m_floor", "emissive": [9.0, 8.0, 7.0], "double_sided": True}],
+        "instances": [{"name": "floor", "primitive": "plane", "material": "m_floor", "scale": [6.0, 1.0, 6.0], "translate": [0.0, -1.1, 0.0]},
+                      {"name": "blob", "primitive": "blob", "material": "m_ss"},
+                      {"name": "quad", "primitive": "plane", "surface": "s_light", "rotate": [180.0, 0.0, 0.0], "translate": [0.5, 3.0, 0.5]}],
+        "lights": [{"type": "directional", "name": "sun", "direction": [-0.4, -1.0, -0.4], "strength": [1.5, 1.4, 1.3]}],
+    }
+    (tmp_path / "mid.json").write_text(json.dumps(scene))
+    sc = spt.load_scene(str(tmp_path / "mid.json"))
+    r = spt.PathTracer(max_depth=6, sampler=spt.SAMPLER_RANDOM, spp=8, seed=9)
+    w, h = 128, 96
+    ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags())
+    got = r.render_shard(sc, spt.OutputConfig(w, h), samples_per_pass=3)
+    assert ref.max() > 0.1
+    nan = np.isnan(ref)
+    assert np.array_equal(nan, np.isnan(got))
+    assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan])
+
+
 def _same_film(got, ref):
     nan = np.isnan(ref)
     assert np.array_equal(nan, np.isnan(got))
