@@ -34,7 +34,24 @@ def f3(rng, lo, hi):
     return [float(x) for x in rng.uniform(lo, hi, 3)]
 
 
-def make_scene(rng):
+_make_scenes = None
+
+
+def _blob(rng, work):
+    """FUZZ_V2: a displaced sphere of a random resolution per seed (120 .. 19 000 triangles): geometry and shading tables
+    land on either side of the LDS thresholds by themselves, deep trees spill the traversal stack"""
+    global _make_scenes
+    if _make_scenes is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_scenes", os.path.join(SCENES, "make_scenes.py"))
+        _make_scenes = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_make_scenes)
+    nu, nv = [(12, 6), (24, 7), (40, 12), (64, 20), (100, 40), (160, 60)][int(rng.integers(0, 6))]
+    _make_scenes.write_displaced_sphere(os.path.join(work, "models", "blob_fuzz.obj"), nu, nv, int(rng.integers(0, 1000)))
+    return "models/blob_fuzz.obj"
+
+
+def make_scene(rng, work=None):
     tex = [{"type": "scalar", "name": "c%d" % k, "value": f3(rng, 0.05, 0.95)} for k in range(4)]
     tex += [{"type": "scalar", "name": "r%d" % k, "value": [float(v)] * 3} for k, v in enumerate((0.0, 0.12, 0.3, 0.55))]
     tex += [{"type": "scalar", "name": "eta", "value": f3(rng, 0.1, 1.6)}, {"type": "scalar", "name": "kk", "value": f3(rng, 1.5, 4.0)},
@@ -125,7 +142,7 @@ def make_scene(rng):
              {"type": "sphere", "name": "off_ball", "center": f3(rng, -0.3, 0.3), "radius": float(rng.uniform(0.3, 0.8))},
              {"type": "trimesh", "name": "cube", "obj_file": "models/cube.obj"},
              {"type": "trimesh", "name": "plane", "obj_file": "models/plane.obj"},
-             {"type": "trimesh", "name": "blob", "obj_file": "models/blob_small.obj"}]
+             {"type": "trimesh", "name": "blob", "obj_file": _blob(rng, work) if (work and os.environ.get("FUZZ_V2")) else "models/blob_small.obj"}]
     use_patches = rng.random() < 0.35
     if use_patches:
         h = rng.uniform(-0.5, 1.2, (4, 4))
@@ -205,7 +222,7 @@ def stage_assets():
 def run_seed(seed, work):
     """-> (ok or None when the loader rejected the scene, one-line description, path of the scene JSON)"""
     rng = np.random.default_rng(1000 + seed)
-    scene = make_scene(rng)
+    scene = make_scene(rng, work)
     path = os.path.join(work, "fuzz_%d.json" % seed)
     with open(path, "w") as fh:
         json.dump(scene, fh, indent=1)
