@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 8
+#define SPT_ABI_VERSION 9
 
 typedef int32_t spt_status;
 enum {
@@ -306,11 +306,16 @@ typedef struct spt_render_params {
                                       rank write its rows in place (one strided DMA, no host-side scatter) */
     float filter_radius;           /* BoxFilter::radius (src/filter/boxf.rs:5-14); read only with SPT_RENDER_BOX_RADIUS,
                                       otherwise 0.5 (every sample of a pixel and no other) */
-    uint32_t reserved0;
+    uint32_t stats_size;           /* sizeof(spt_render_stats) AS THE CALLER WAS COMPILED (ABI v9).  spt_render writes at most
+                                      this many bytes of `stats`, so a caller built against an older, shorter struct is never
+                                      written past its end (the struct only ever grows at the tail).  Must be set when `stats`
+                                      is not NULL: 0 with a non-NULL `stats` is SPT_ERR_INVALID_ARG */
 } spt_render_params;
 enum {
     SPT_RENDER_PROFILE = 1u,       /* time each kernel class with HIP events */
-    SPT_RENDER_BOX_RADIUS = 2u     /* filter_radius is set */
+    SPT_RENDER_BOX_RADIUS = 2u,    /* filter_radius is set */
+    SPT_RENDER_COUNT_VISITS = 4u   /* count BVH node / triangle / instance visits on the device (stats->*_visits); the counting
+                                      kernels are separate instantiations, slower by a few per cent: measurement runs only */
 };
 
 #define SPT_N_KERNELS 7
@@ -329,6 +334,11 @@ typedef struct spt_render_stats {
     uint64_t vertices_second;      /* path vertices of bounce 1 (= extension rays of bounce 0 that were kept) */
     uint64_t live_samples;         /* chunked k_primary: camera samples of pixels inside the screen-space bound, each of
                                       which owns a radiance slot; 0 when the un-chunked kernel ran */
+    /* ABI v9, SPT_RENDER_COUNT_VISITS only (0 otherwise): what the traversal kernels fetched, summed over all ray segments */
+    uint64_t node_visits;          /* BVH node records fetched (TLAS + BLAS; one record = one multi-child node)      */
+    uint64_t tri_tests;            /* triangle records fetched and tested                                            */
+    uint64_t instance_visits;      /* instance records fetched (ray transformed into object space)                   */
+    uint64_t node_bytes;           /* bytes of the node records above (record sizes differ between the node formats)  */
 } spt_render_stats;
 
 /* Closest-hit record: what BvhAccel/Group::intersect leave in `Intersection`

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 8
+SPT_ABI_VERSION = 9
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -157,6 +157,7 @@ class Camera(C.Structure):
 SAMPLER_RANDOM, SAMPLER_JITTERED, SAMPLER_RECURRENCE = 0, 1, 2
 RENDER_PROFILE = 1
 RENDER_BOX_RADIUS = 2
+RENDER_COUNT_VISITS = 4
 N_KERNELS = 7
 KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other", "shade_first")
 
@@ -166,14 +167,15 @@ class RenderParams(C.Structure):
                 ("sampler", C.c_uint32), ("division_x", C.c_uint32), ("division_y", C.c_uint32),
                 ("seed", C.c_uint64), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
                 ("strip_rows", C.c_uint32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32),
-                ("out_strip_stride", C.c_uint64), ("filter_radius", C.c_float), ("reserved0", C.c_uint32)]
+                ("out_strip_stride", C.c_uint64), ("filter_radius", C.c_float), ("stats_size", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments_closest", C.c_uint64), ("segments_shadow", C.c_uint64),
                 ("gpu_ms", C.c_double), ("kernel_ms", C.c_double * N_KERNELS),
                 ("kernel_launches", C.c_uint32 * N_KERNELS), ("primary_hits", C.c_uint64),
-                ("path_vertices", C.c_uint64), ("shadow_first", C.c_uint64), ("vertices_second", C.c_uint64), ("live_samples", C.c_uint64)]
+                ("path_vertices", C.c_uint64), ("shadow_first", C.c_uint64), ("vertices_second", C.c_uint64), ("live_samples", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("instance_visits", C.c_uint64), ("node_bytes", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("instance", "<i4"), ("prim", "<i4"), ("v", "<f4"), ("w", "<f4")])
@@ -227,6 +229,9 @@ def hip_lib() -> C.CDLL:
         lib = _load("libspt_hip.so")
         lib.spt_last_error.restype = C.c_char_p
         lib.spt_abi_version.restype = C.c_uint32
+        got = lib.spt_abi_version()
+        if got != SPT_ABI_VERSION:   # the ctypes mirrors above would mis-size every struct: fail before any call uses them
+            raise SptError(1, "libspt_hip.so exports ABI version %d, this binding mirrors version %d (rebuild: `make`)" % (got, SPT_ABI_VERSION))
         lib.spt_device_count.argtypes = [C.POINTER(C.c_int32)]
         lib.spt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(C.c_void_p)]
         lib.spt_scene_destroy.argtypes = [C.c_void_p]
@@ -413,6 +418,7 @@ class PathTracer:
         p.seed = self.seed
         p.shard_index, p.shard_count, p.strip_rows = shard_index, shard_count, strip_rows
         p.samples_per_pass, p.flags = samples_per_pass, flags
+        p.stats_size = C.sizeof(RenderStats)
         if self.filter_radius != 0.5:
             # BoxFilter of any radius (src/filter/boxf.rs): Film::filter_pixel sums the UNWEIGHTED colours of the
             # (2 ceil(radius - 0.5) + 1)^2 pixels around a pixel and divides by the number of those samples whose

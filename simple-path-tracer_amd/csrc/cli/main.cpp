@@ -42,6 +42,11 @@ int main(int argc, char** argv) {
     }
     if (scene_path.empty() || renderer_path.empty() || out_path.empty()) { usage(); return 2; }
 
+    // this binary and the library it found at run time must agree on the struct layouts of include/spt_abi.h
+    if (spt_abi_version() != SPT_ABI_VERSION) {
+        std::fprintf(stderr, "Error: libspt_hip.so exports ABI version %u, this program was built against %u\n", spt_abi_version(), (unsigned)SPT_ABI_VERSION);
+        return 1;
+    }
     std::fprintf(stderr, "Loading from JSON and building aggregate...\n");
     spt_host_scene* hs = nullptr;
     if (spt_host_load_scene(scene_path.c_str(), &hs) != SPT_OK) {
@@ -75,6 +80,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "Scene JSON is loaded successfully. Rendering...\n");
     std::vector<float> film((size_t)width * height * 3);
     spt_render_stats st;
+    params.stats_size = (uint32_t)sizeof st;   // the library writes no more than this (ABI v9)
     auto t0 = std::chrono::steady_clock::now();
     if (spt_render(ds, &cam, &params, film.data(), &st) != SPT_OK) {
         std::fprintf(stderr, "Error: %s\n", spt_last_error());

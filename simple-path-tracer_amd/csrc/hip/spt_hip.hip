@@ -559,6 +559,15 @@ void validate(const spt_scene_desc& s) {
         }
         if (in.surface >= s.n_surfaces) fail(SPT_ERR_INVALID_ARG, "scene desc: instance surface index out of range");
         if (in.light >= (int32_t)s.n_lights) fail(SPT_ERR_INVALID_ARG, "scene desc: instance light index out of range");
+        if (in.light >= 0 && (s.lights[in.light].type != SPT_LIGHT_SHAPE || s.lights[in.light].instance != i))
+            fail(SPT_ERR_INVALID_ARG, "scene desc: instance light does not name the shape light of this instance");
+        // pdf_shape_light of the power_is sampler looks the instance up in its light map (power_is.rs:84-86; the reference
+        // panics on a missing key): an emissive instance that is not a light would index light_alias.props[-1]
+        if (s.light_sampler == SPT_LIGHT_SAMPLER_POWER_IS && in.light < 0) {
+            const spt_surface& sf = s.surfaces[in.surface];
+            if (0.299f * sf.emissive[0] + 0.587f * sf.emissive[1] + 0.114f * sf.emissive[2] > 0.0f)
+                fail(SPT_ERR_INVALID_ARG, "scene desc: power_is light sampler and an emissive instance without a shape light");
+        }
     }
     for (uint32_t i = 0; i < s.n_meshes; ++i) {
         const spt_mesh& m = s.meshes[i];
@@ -1078,7 +1087,22 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         if ((uint64_t)p.width * p.height > 0xffffffffull) fail(SPT_ERR_UNSUPPORTED, "render: more than 2^32 pixels");
         const uint32_t own_rows = shard_row_count(p);
         const uint64_t own_pix64 = (uint64_t)own_rows * p.width;
-        if (stats) std::memset(stats, 0, sizeof *stats);
+        // `stats` belongs to a caller that may have been compiled against an older (shorter) spt_render_stats: fill a
+        // local copy and hand back only the bytes the caller says it has (spt_render_params::stats_size, ABI v9)
+        spt_render_stats* const stats_out = stats;
+        spt_render_stats stats_local;
+        std::memset(&stats_local, 0, sizeof stats_local);
+        size_t stats_bytes = 0;
+        if (stats_out) {
+            if (p.stats_size < 8u) fail(SPT_ERR_INVALID_ARG, "render: stats given but params.stats_size is not set (caller built against ABI < 9?)");
+            stats_bytes = std::min<size_t>(p.stats_size, sizeof stats_local);
+            std::memset(stats_out, 0, stats_bytes);
+            stats = &stats_local;
+        }
+        struct StatsCopy {   // copies on every exit path that got this far, error paths included
+            spt_render_stats* dst; const spt_render_stats* src; size_t n;
+            ~StatsCopy() { if (dst) std::memcpy(dst, src, n); }
+        } stats_copy{stats_out, &stats_local, stats_bytes};
         if (own_pix64 == 0) return SPT_OK;
         if (own_pix64 > 0x7fffffffull) fail(SPT_ERR_UNSUPPORTED, "render: shard larger than 2^31 pixels");
         const uint32_t own_pix = (uint32_t)own_pix64;

@@ -1592,8 +1592,12 @@ struct SceneBuilder {
         }
         for (auto& kv : instances) {
             const InstRec& r = kv.second;
+            // Surface::is_emissive (surface.rs:45-47) looks at the CONSTANT emissive only: a surface with emissive > 0 and an
+            // all-black emissive_map is still a light (it takes a slot of the sampler and of the alias table); the map's
+            // average only enters ShapeLight::power (shape_light.rs:79-82)
+            const spt_surface& sfc = hs.surfaces[r.inst.surface];
             V3 em = avg_emissive[r.inst.surface];
-            if (luminance(em) > 0.0f) {  // Surface::is_emissive
+            if (luminance(V3{sfc.emissive[0], sfc.emissive[1], sfc.emissive[2]}) > 0.0f) {
                 spt_light l;
                 std::memset(&l, 0, sizeof l);
                 l.type = SPT_LIGHT_SHAPE;

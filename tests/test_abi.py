@@ -103,6 +103,51 @@ def test_invalid_descriptors_are_rejected_before_touching_a_device():
     assert rows.value == len(spt.shard_rows(37, 1, 3, 4))
 
 
+@pytest.mark.skipif(not os.path.exists(HIP_SO), reason="libspt_hip.so not built")
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """A caller whose struct mirrors belong to another header version must fail before any call uses them (a stale CLI
+    built against a shorter spt_render_stats once had its stack smashed by spt_render)."""
+    monkeypatch.setattr(spt, "_hip_lib", None)
+    monkeypatch.setattr(spt, "SPT_ABI_VERSION", spt.SPT_ABI_VERSION + 1)
+    with pytest.raises(spt.SptError) as e:
+        spt.hip_lib()
+    assert "ABI version" in str(e.value)
+    monkeypatch.undo()
+    assert spt.hip_lib().spt_abi_version() == spt.SPT_ABI_VERSION
+    # header, python mirror and the struct tail added with v9 agree
+    hdr = open(os.path.join(_util.ROOT, "include", "spt_abi.h")).read()
+    assert "#define SPT_ABI_VERSION %d" % spt.SPT_ABI_VERSION in hdr
+    assert spt.RenderStats.node_bytes.offset + 8 == C.sizeof(spt.RenderStats)
+    assert spt.RenderParams.stats_size.offset + 4 == C.sizeof(spt.RenderParams)
+    # the CLI checks the version of the library it found before doing anything else
+    src = open(os.path.join(_util.PKG_DIR, "csrc", "cli", "main.cpp")).read()
+    assert "spt_abi_version() != SPT_ABI_VERSION" in src and "params.stats_size" in src
+
+
+@pytest.mark.gpu
+def test_render_never_writes_past_the_callers_stats_struct():
+    """spt_render_params::stats_size (ABI v9): a caller compiled against a shorter spt_render_stats gets only that many bytes."""
+    lib = spt.hip_lib()
+    sc = spt.load_scene(os.path.join(_util.SCENES, "cfg2_cube.json"))
+    ds = sc.device_scene(0)
+    cam = sc.get_camera(None)
+    r = spt.PathTracer(spp=2)
+    p = r.params(32, 32)
+    out = np.zeros((32, 32, 3), dtype=np.float32)
+    full = C.sizeof(spt.RenderStats)
+    buf = (C.c_uint8 * (full + 64))()
+    stats = C.cast(buf, C.POINTER(spt.RenderStats))
+    for short in (full, spt.RenderStats.primary_hits.offset, 24):   # today's struct, the round-1 prefix, three counters only
+        C.memset(buf, 0xAB, len(buf))
+        p.stats_size = short
+        assert lib.spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, stats) == 0
+        assert stats.contents.samples == 32 * 32 * 2
+        assert bytes(buf[short:]) == b"\xab" * (len(buf) - short), "spt_render wrote past stats_size = %d" % short
+    p.stats_size = 0
+    assert lib.spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, stats) == 1 and b"stats_size" in lib.spt_last_error()
+    assert lib.spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, None) == 0   # no stats: nothing to size
+
+
 def test_product_sources_never_reference_the_oracle():
     """A product path that routes through the oracle voids every parity claim."""
     bad = []

@@ -39,7 +39,15 @@ def test_two_ranks_assemble_one_film_in_shared_memory(scene_name, camera, radius
         p.start()
     for p in procs:
         p.join(timeout=240)
+    # a rank that is still alive hangs (GPU hang, deadlock): kill exactly that child - it would otherwise keep the GPU and
+    # its page-locked mapping of the film for the rest of the lease - and fail with the ranks' exit states
+    hung = [k for k, p in enumerate(procs) if p.is_alive()]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join()
     try:
+        assert not hung, "rank(s) %s did not finish within 240 s and were killed" % hung
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         sc = spt.load_scene(os.path.join(_util.SCENES, scene_name))
         r = spt.PathTracer(max_depth=6, sampler=spt.SAMPLER_RANDOM, spp=spp, seed=77, filter_radius=radius)

@@ -156,6 +156,25 @@ def test_lights_env_first_then_shape_lights_and_power_is_table(tmp_path):
     assert abs(lamp["power"] - 4 * np.pi * 0.35 ** 2 * (0.299 * 14 + 0.587 * 12 + 0.114 * 9)) < 0.05 * lamp["power"]
 
 
+def test_light_membership_looks_at_the_constant_emissive_only(tmp_path):
+    """Surface::is_emissive (surface.rs:45-47) tests the constant `emissive`; an all-black emissive_map does not take the
+    instance out of the light list (scene_resources.rs:112-120), it only zeroes ShapeLight::power (shape_light.rs:79-82)."""
+    scene = json.loads(json.dumps(BASE))
+    scene["textures"].append({"type": "scalar", "name": "black", "value": [0.0, 0.0, 0.0]})
+    scene["surfaces"] = [{"name": "glow", "material": "m", "emissive": [5.0, 4.0, 3.0], "emissive_map": "black"},
+                         {"name": "dark", "material": "m", "emissive": [0.0, 0.0, 0.0]}]
+    scene["instances"] = [{"name": "a", "primitive": "s", "surface": "glow"}, {"name": "b", "primitive": "s", "surface": "dark", "translate": [3.0, 0.0, 0.0]},
+                          {"name": "c", "primitive": "s", "material": "m", "translate": [-3.0, 0.0, 0.0]}]
+    scene["light_sampler"] = "uniform"
+    sc = load(tmp_path, scene)
+    lights, inst = sc.array("lights"), sc.array("instances")
+    assert lights["type"].tolist() == [0, 3]                  # the directional light, then ONE shape light
+    li = int(lights["instance"][1])
+    assert inst["light"][li] == 1 and sorted(inst["light"].tolist()) == [-1, -1, 1]
+    assert np.allclose(sc.array("surfaces")["emissive"][inst["surface"][li]], [5.0, 4.0, 3.0])
+    assert lights["power"][1] == 0.0                          # area * luminance(emissive * average(black map))
+
+
 def test_medium_sigma_s_is_read_from_sigma_a_quirk():
     sc = spt.load_scene(os.path.join(_util.SCENES, "t_medium.json"))
     fog = sc.array("mediums")[0]
