@@ -19,11 +19,12 @@ HOST_HDR := $(wildcard $(PKG)/csrc/host/*.hpp) $(wildcard include/*.h)
 HIP_SRC  := $(wildcard $(PKG)/csrc/hip/*.hip)
 HIP_HDR  := $(wildcard $(PKG)/csrc/hip/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip cli oracle clean
+.PHONY: all host hip hip-plain cli oracle clean
 all: host oracle hip cli
 
 host: $(LIBDIR)/libspt_host.so
 hip: $(LIBDIR)/libspt_hip.so $(LIBDIR)/libspt_hip_bez.so
+hip-plain: $(LIBDIR)/libspt_hip.so   # kernel iteration: the library every scene without Bezier patches uses
 cli: $(LIBDIR)/spt
 oracle:
 	$(MAKE) -C oracle
@@ -32,17 +33,31 @@ $(LIBDIR)/libspt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
 
-$(LIBDIR)/libspt_hip.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -Wl,-Bsymbolic -o $@ $(HIP_SRC) -ldl
+# one object per translation unit (spt_hip.hip = host side + film kernels, inst_*.hip = groups of kernel instantiations,
+# see csrc/hip/kernel_list.h), compiled side by side with `make -jN`
+OBJDIR   := build/hip
+HIP_OBJ     := $(patsubst $(PKG)/csrc/hip/%.hip,$(OBJDIR)/plain/%.o,$(HIP_SRC))
+HIP_OBJ_BEZ := $(patsubst $(PKG)/csrc/hip/%.hip,$(OBJDIR)/bez/%.o,$(HIP_SRC))
 
-# the same source with the CubicBezier primitive compiled in; opened by libspt_hip.so for scenes with patches
-$(LIBDIR)/libspt_hip_bez.so: $(HIP_SRC) $(HIP_HDR)
+$(OBJDIR)/plain/%.o: $(PKG)/csrc/hip/%.hip $(HIP_HDR)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+# the same sources with the CubicBezier primitive compiled in; the library is opened by libspt_hip.so for scenes with patches
+$(OBJDIR)/bez/%.o: $(PKG)/csrc/hip/%.hip $(HIP_HDR)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -DSPT_WITH_BEZIER=1 -c -o $@ $<
+
+$(LIBDIR)/libspt_hip.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DSPT_WITH_BEZIER=1 -shared -Wl,-Bsymbolic -o $@ $(HIP_SRC) -ldl
+	$(HIPCC) $(HIPFLAGS) -shared -Wl,-Bsymbolic -o $@ $(HIP_OBJ) -ldl
+
+$(LIBDIR)/libspt_hip_bez.so: $(HIP_OBJ_BEZ)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -Wl,-Bsymbolic -o $@ $(HIP_OBJ_BEZ) -ldl
 
 $(LIBDIR)/spt: $(PKG)/csrc/cli/main.cpp $(wildcard include/*.h) $(LIBDIR)/libspt_host.so $(LIBDIR)/libspt_hip.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lspt_host -lspt_hip -Wl,-rpath,'$$ORIGIN'
 
 clean:
-	rm -rf $(LIBDIR) oracle/*.so oracle/_ref
+	rm -rf $(LIBDIR) build oracle/*.so oracle/_ref

@@ -1,26 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s of the path-tracing hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): the reference's scenes/test_scene_01.json
-(re-authored as scenes_amd/cfg2_cube.json: 12-triangle Lambert cube, one directional
-light) with scenes/pt.json (max_depth 8, recurrence sampler, box filter 0.5) at
-1024x1024, 256 spp on one GPU.  A "step" is one full render of that image.
+Workload (BASELINE.json metric / configs[1]): the reference's scenes/test_scene_01.json (scenes_amd/cfg2_cube.json:
+12-triangle Lambert cube, one directional light) with scenes/pt.json (max_depth 8, recurrence sampler, box filter
+0.5) at 1024x1024, 256 spp.  A "step" is one full render of that image.
 
-N > 1 (weak scaling): the image stays 1024x1024 and spp becomes 256*N; image rows are
-sharded over the ranks in interleaved 16-row strips, so every rank traces the same
-268.4 M camera samples per step with the same scene coverage.  There is no data-path
-collective; the shards are gathered on the host of rank 0 inside the timed region.
+N > 1 is STRONG scaling of that same run: the image rows are dealt to the ranks in interleaved 16-row strips, every
+rank traces its 1/N of the 268.4 M camera samples with a full scene replica and DMAs its rows straight into one
+shared-memory film (no data-path collective).  `value` = 268.4 M samples x steps / max-over-ranks wall time.
+Secondary entries of the same line (their own short timed regions, outside `value`): the weak-scaling figure
+(spp = 256 N, the same work per GPU as at N = 1) and BASELINE configs[2] (4096x4096 @ 1024 spp over N ranks); at
+N = 1 also `other_configs` (configs[3] and one GPU's share of configs[4]) and `parity` against the CPU oracle.
 
-Launch: `python bench.py` (N=1) or, for N>1,
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
- --master-port P bench.py --gpus N --steps K --warmup W`.
-PyTorch is used only for the barrier / synchronize / gather plumbing.
+Launch: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the parent process only spawns
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+BEFORE anything touches the GPU and relays its output; launching it under torch.distributed.run directly (RANK /
+WORLD_SIZE set) works too.  PyTorch is only the barrier / synchronize / max-reduce plumbing.
 """
 import argparse
-import ctypes as C
-import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def load_pkg():
+    import importlib.util
     name = "simple_path_tracer_amd"
     if name in sys.modules:
         return sys.modules[name]
@@ -43,16 +45,23 @@ def load_pkg():
 # record sizes of the queue layouts in simple-path-tracer_amd/csrc/hip/kernels.h (bytes)
 S_PATH, S_HIT, S_SHADOW, S_RAD = 72, 20, 48, 12
 S_PATH0 = 16  # compact bounce-0 record: direction + slot
+# geometry records (SURVEY 8d / DESIGN.md section 3): node, triangle positions, triangle attributes, instance
+S_NODE, S_TRI, S_ATTR, S_INST = 64, 48, 144, 192
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(spt, scene, renderer, width, height, budget_s=15.0):
-    """Oracle (CPU restatement of the reference loop) timed on this box's host cores, on a
-    bounded sample of the SAME workload: the full 1024x1024 frame at a reduced spp."""
+def oracle_util():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _util
-
     _util.ensure_cpu_build()
+    return _util
+
+
+def cpu_baseline(spt, scene, renderer, width, height, budget_s=15.0):
+    """Oracle (CPU restatement of the reference loop, reference-faithful mode: exact six-division slab test, the reference's
+    visit order) timed on this box's host cores, on a bounded sample of the SAME workload: the full frame at the largest spp
+    that fits the budget (the full 256 spp on a many-core host).  Returns the line, the film and the renderer used."""
+    _util = oracle_util()
     cores = len(os.sched_getaffinity(0))
     threads = 2 * cores  # reference layout: num_cpus * 2 threads over row bands (pt.rs:243)
     probe = spt.PathTracer(renderer.max_depth, renderer.sampler, 1, 0, 0, renderer.filter_radius, renderer.seed)
@@ -62,36 +71,69 @@ def cpu_baseline(spt, scene, renderer, width, height, budget_s=15.0):
     spp = int(max(1, min(renderer.spp, budget_s / dt)))
     run = spt.PathTracer(renderer.max_depth, renderer.sampler, spp, 0, 0, renderer.filter_radius, renderer.seed)
     t0 = time.perf_counter()
-    _, st = _util.oracle_render(scene, run, width, height, threads=threads)
+    film, st = _util.oracle_render(scene, run, width, height, threads=threads)
     dt = time.perf_counter() - t0
     return {
         "value": round(st.samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "threads": threads,
         "kind": "port",
         "sample": "%dx%d @ %d spp of the same scene/renderer (%.1f s, %d samples)" % (width, height, spp, dt, st.samples),
-    }, st
+    }, film, run
+
+
+def film_parity(spt, got, ref):
+    """The metric's parity figure: per-pixel mean L1 on linear float radiance, plus what bit-exactness adds."""
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    ok = ~(nan_g | nan_r)
+    u8g, u8r = spt.film_to_rgb8(got).astype(np.int16), spt.film_to_rgb8(ref).astype(np.int16)
+    return {"mean_L1": float(np.abs(got - ref)[ok].mean()) if ok.any() else None,
+            "words_differ": int((got.view(np.uint32) != ref.view(np.uint32))[ok].sum()), "words": int(got.size),
+            "nan_equal": bool(np.array_equal(nan_g, nan_r)), "nan_words": int(nan_r.sum()),
+            "u8_pixels_differ_gt1": int((np.abs(u8g - u8r) > 1).any(axis=2).sum())}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` as typed: this process never initialises the GPU; it starts the N ranks as a child
+    (torch.distributed.run) and passes their stdout (one JSON line from rank 0) and exit code on."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU-share")
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel of the image (split over the ranks)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes_amd", "cfg2_cube.json"))
     ap.add_argument("--renderer", default=os.path.join(ROOT, "scenes_amd", "pt.json"))
     ap.add_argument("--samples-per-pass", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
-    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (weak scaling, configs[2], other_configs)")
+    ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--backend", default="gloo",
-                    help="torch.distributed backend of the control plane (N > 1): a barrier, one max-reduce of a double and one "
-                         "name broadcast.  The data path has no collective (every rank writes its rows into the shared film), so "
-                         "nothing needs RCCL; pass cpu:gloo,cuda:nccl to run the barriers over RCCL / xGMI instead")
+                    help="torch.distributed backend of the control plane (N > 1): two barriers and one max-reduce of a double per "
+                         "timed region, one name broadcast.  The data path has no collective (every rank writes its rows into the "
+                         "shared film), so nothing needs RCCL; pass cpu:gloo,cuda:nccl to run the barriers over RCCL / xGMI instead")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))     # nothing above imported torch or opened the HIP runtime
 
     import torch
 
@@ -99,7 +141,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
     if args.single_device:
@@ -124,12 +166,8 @@ def main():
 
     spt = load_pkg()
     scene = spt.load_scene(args.scene)
-    renderer = spt.load_renderer(args.renderer, seed=1)
-    renderer.spp = args.spp * world
-    cfg = spt.OutputConfig(args.width, args.height)
     strip_rows = 16
-    # scene upload (excluded from the timed region: inputs resident in HBM)
-    scene.device_scene(local_rank)
+    scene.device_scene(local_rank)   # scene upload: outside every timed region (inputs resident in HBM)
 
     def barrier():
         torch.cuda.synchronize()          # this rank's GPU work is done ...
@@ -140,54 +178,92 @@ def main():
                 dist.barrier()            # ... and so is everybody else's
         torch.cuda.synchronize()
 
-    film = None
-    if dist is not None:
-        name = [None]
-        if rank == 0:
-            film = spt.SharedFilm(args.height, args.width, create=True)
-            name[0] = film.name
-        dist.broadcast_object_list(name, src=0)
-        if rank != 0:
-            film = spt.SharedFilm(args.height, args.width, name=name[0])
-        film.pin()
+    films = {}
 
-    kernel_ms = np.zeros(spt.N_KERNELS)
-    kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
-    stats_last = None
+    def shared_film(h, w):
+        """One (h, w, 3) f32 film in POSIX shared memory per image size, page-locked by every rank (N > 1)."""
+        if dist is None:
+            return None
+        if (h, w) not in films:
+            name = [None]
+            f = None
+            if rank == 0:
+                f = spt.SharedFilm(h, w, create=True)
+                name[0] = f.name
+            dist.broadcast_object_list(name, src=0)
+            if rank != 0:
+                f = spt.SharedFilm(h, w, name=name[0])
+            f.pin()
+            films[(h, w)] = f
+        return films[(h, w)]
 
-    def step(profiled):
-        nonlocal stats_last
-        # N > 1: every rank's strips are DMA-ed straight into the node's shared-memory film (no collective, no host-side
-        # scatter); N = 1: the pinned shard buffer is the image
-        shard = renderer.render_shard(scene, cfg, device=local_rank, shard_index=rank, shard_count=world,
-                                      strip_rows=strip_rows, samples_per_pass=args.samples_per_pass,
-                                      profile=profiled, reuse_output=True, film=film.film if film is not None else None)
-        st = renderer.last_stats
-        if profiled:
-            for k in range(spt.N_KERNELS):
-                kernel_ms[k] += st.kernel_ms[k]
-                kernel_launches[k] += st.kernel_launches[k]
-        stats_last = st
-        return shard
+    def timed(renderer, sc, cfg, steps, warmup, profile_steps=0):
+        """`steps` renders of this rank's shard of `cfg`, bracketed by barrier + synchronize on both sides, max over ranks.
+        Returns (seconds, last stats, per-class kernel ms, per-class launches) - the kernel times come from separate,
+        untimed steps right after the timed region (an event pair around every launch costs ~7 % of a step)."""
+        film = shared_film(cfg.height, cfg.width)
+        kernel_ms = np.zeros(spt.N_KERNELS)
+        kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(False)
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-kernel HIP-event timing on the render stream: separate, untimed steps right after the timed
-    # region (an event pair around every launch costs ~7 % of a step, so it stays out of `value`)
-    if not args.no_profile:
-        for _ in range(args.profile_steps):
-            step(True)
+        def step(profiled):
+            # N > 1: this rank's strips are DMA-ed straight into the node's shared-memory film (no collective, no host-side
+            # scatter); N = 1: the pinned shard buffer is the image
+            renderer.render_shard(sc, cfg, device=local_rank, shard_index=rank, shard_count=world, strip_rows=strip_rows,
+                                  samples_per_pass=args.samples_per_pass, profile=profiled, reuse_output=True,
+                                  film=film.film if film is not None else None)
+            st = renderer.last_stats
+            if profiled:
+                for k in range(spt.N_KERNELS):
+                    kernel_ms[k] += st.kernel_ms[k]
+                    kernel_launches[k] += st.kernel_launches[k]
+            return st
+
+        for _ in range(warmup):
+            step(False)
         barrier()
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        t0 = time.perf_counter()
+        st = None
+        for _ in range(steps):
+            st = step(False)
+        barrier()
+        dt = time.perf_counter() - t0
+        for _ in range(profile_steps):
+            step(True)
+        if profile_steps:
+            barrier()
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, st, kernel_ms, kernel_launches
+
+    # ---- the metric's run: 1024 x 1024 @ 256 spp over `world` ranks (strong scaling) ----------------------------------
+    renderer = spt.load_renderer(args.renderer, seed=1)
+    renderer.spp = args.spp
+    cfg = spt.OutputConfig(args.width, args.height)
+    n_prof = 0 if args.no_profile else max(args.profile_steps, 1)
+    dt, stats_last, kernel_ms, kernel_launches = timed(renderer, scene, cfg, args.steps, args.warmup, n_prof)
+
+    # ---- secondary entries: their own timed regions, never part of `value` -------------------------------------------
+    secondary = {}
+    if not args.no_secondary:
+        if world > 1:
+            weak = spt.load_renderer(args.renderer, seed=1)
+            weak.spp = args.spp * world
+            k = max(3, min(args.steps, 40))
+            wdt, _, _, _ = timed(weak, scene, cfg, k, 1)
+            secondary["weak_scaling"] = {
+                "workload": "%dx%d @ %d spp (= %d spp per GPU-share: the N = 1 work on every GPU)" % (args.width, args.height, weak.spp, args.spp),
+                "value": round(args.width * args.height * weak.spp * k / wdt / 1e6, 2), "unit": "Msamples/s", "steps": k,
+                "ms_per_step": round(wdt / k * 1e3, 3), "scaling": "weak"}
+        big = spt.load_renderer(args.renderer, seed=1)
+        big.spp = 1024
+        bcfg = spt.OutputConfig(4096, 4096)
+        k = 3 if world > 1 else 2
+        bdt, _, _, _ = timed(big, scene, bcfg, k, 1)
+        secondary["configs2_cube_4096x4096_1024spp"] = {
+            "workload": "BASELINE configs[2]: the same scene at 4096x4096 @ 1024 spp, rows dealt to %d rank(s)" % world,
+            "value": round(4096 * 4096 * 1024 * k / bdt / 1e6, 2), "unit": "Msamples/s", "steps": k, "ms_per_step": round(bdt / k * 1e3, 2)}
 
     if rank == 0:
         samples_per_step = args.width * args.height * renderer.spp  # all ranks together
@@ -195,11 +271,10 @@ def main():
         value = samples_per_step * args.steps / dt / 1e6
         st = stats_last                                              # rank 0's shard, one step
         n_launch = np.maximum(kernel_launches, 1)
-        n_prof = max(args.profile_steps, 1)
         smp, seg_c, seg_s = st.samples, st.segments_closest, st.segments_shadow
         ext, hits0, verts = seg_c - smp, st.primary_hits, st.path_vertices
         n_pix = len(spt.shard_rows(args.height, 0, world, strip_rows)) * args.width
-        passes = max(int(kernel_launches[0]) // n_prof, 1)
+        passes = max(int(kernel_launches[0]) // max(n_prof, 1), 1)
         RNAME = {"shade_first": "k_shade"}                           # kernel symbol behind a class name
         # ALGORITHMIC bytes each kernel class moves per step (DESIGN.md "Kernels and rooflines"):
         # queue records written/read once + radiance-slot / film read-modify-writes; scene geometry of
@@ -241,48 +316,149 @@ def main():
         pipeline_bytes = sum(alg[n] for n in kern)                     # only the kernel classes that ran (fused: no shadow / extend)
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected in a
         # separate rocprofv3 --pmc run of this same command and committed under profiles/ (tools/pmc_traffic.py)
-        traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r01_traffic_bench.json")
-        if os.path.exists(traffic_src) and world == 1 and args.samples_per_pass == 0 and args.spp == 256:
-            tk = json.load(open(traffic_src))["kernels"].get("k_" + dom_name)   # "k_shade_first": bounce-0 instances
+        traffic, traffic_file = None, None
+        for cand in ("r02_traffic_bench.json", "r01_traffic_bench.json"):
+            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                traffic_file = cand
+                break
+        if traffic_file and world == 1 and args.samples_per_pass == 0 and args.spp == 256:
+            tk = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["kernels"].get("k_" + dom_name)   # "k_shade_first": bounce-0 instances
             if tk and tk["launches"] == dom.get("launches_per_step"):   # (per-template-instance entries: see tools/pmc_traffic.py)
                 traffic = round(tk["hbm_bytes_per_launch"] / 1e6, 3)
         roofline = {
             "bound": "hbm", "kernel": RNAME.get(dom_name, "k_" + dom_name) + (" (bounce 0)" if dom_name == "shade_first" else ""), "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["frac"], "traffic": traffic, "traffic_unit": "MB per launch (PMC, profiles/r01_traffic_bench.json)",
+            "frac": dom["frac"], "traffic": traffic, "traffic_unit": "MB per launch (PMC, profiles/%s)" % traffic_file,
             "avg_launch_ms": dom["avg_launch_ms"], "alg_MB_per_launch": dom["alg_MB_per_launch"],
+            "limiter": "VALU instruction issue, not HBM: the scene is LDS-resident and a missing ray touches no memory at all (DESIGN.md section 6)",
             "kernels": kern,
             "pipeline": {"alg_bytes_per_sample": round(pipeline_bytes / max(smp, 1), 2),
                          "GBps_at_value": round(pipeline_bytes / max(smp, 1) * value * 1e6 / world / 1e9, 1)},
-            "note": "HIP-event kernel times from %d untimed steps after the timed region; the path is ALU/latency-bound "
-                    "(tiny scene, misses never touch HBM), so the HBM fraction is low by design - see DESIGN.md" % n_prof,
+            "note": "HIP-event kernel times from %d untimed steps after the timed region (rank 0's shard)" % n_prof,
         }
         out = {
             "metric": "Msamples/sec (whole node) at 1024x1024/256spp; per-pixel mean L1 vs CPU ref",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "scenes_amd/cfg2_cube.json (= reference scenes/test_scene_01.json) + pt.json, "
-                                   "%dx%d @ %d spp (%d spp per GPU-share), max_depth %d, recurrence sampler"
-                                   % (args.width, args.height, renderer.spp, args.spp, renderer.max_depth),
+                                   "%dx%d @ %d spp, max_depth %d, recurrence sampler; the SAME image for every N (%d row strips of 16 "
+                                   "dealt round-robin to %d rank(s))" % (args.width, args.height, renderer.spp, renderer.max_depth,
+                                                                      (args.height + strip_rows - 1) // strip_rows, world),
                        "width": args.width, "height": args.height, "spp": renderer.spp, "seed": 1,
+                       "samples_per_step": samples_per_step,
                        "sharding": "interleaved %d-row strips over %d rank(s); each rank writes its rows into one shared-memory film "
                                    "(no collective)" % (strip_rows, world),
+                       "per_rank": {"samples": int(smp), "live_samples": int(st.live_samples),
+                                    "note": "live = camera samples of pixels inside the scene's screen-space bound; the others are provably "
+                                            "black, move no bytes and run no sample loop (bit-identical film; SPT_NO_PIXEL_CULL=1 for the A/B)"},
                        "segments_per_sample": round((seg_c + seg_s) / max(smp, 1), 4),
-                       "primary_hit_fraction": round(hits0 / max(smp, 1), 4)},
+                       "primary_hit_fraction": round(hits0 / max(smp, 1), 4),
+                       "what_bounds_large_N": "a rank's share is 1/N of ~4.1 ms of kernels; the per-step fixed cost (counter memset, ~10 "
+                                              "launches of ~5 us, strided D2H of the rank's rows, one stream sync) does not shrink with N"},
             "roofline": roofline,
         }
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            base, ost = cpu_baseline(spt, scene, spt.load_renderer(args.renderer, seed=1), args.width, args.height)
+            ref_renderer = spt.load_renderer(args.renderer, seed=1)
+            ref_renderer.spp = args.spp
+            base, ref_film, ran = cpu_baseline(spt, scene, ref_renderer, args.width, args.height)
             out["cpu_baseline"] = base
             out["config"]["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
+            # parity of the metric: GPU film vs the oracle film cpu_baseline() just rendered (same spp), and vs the oracle
+            # in the configuration the kernels reproduce bit for bit (no box culling, order-independent tie rule)
+            _util = oracle_util()
+            gpu_film = ran.render_shard(scene, cfg, device=local_rank).copy()
+            exhaustive, _ = _util.oracle_render(scene, ran, args.width, args.height, flags=_util.ORACLE_EXHAUSTIVE,
+                                                threads=2 * len(os.sched_getaffinity(0)))
+            out["parity"] = {"spp": ran.spp, "tolerance_mean_L1": 1e-3,
+                             "vs_reference_walk": film_parity(spt, gpu_film, ref_film),
+                             "vs_exhaustive_oracle": film_parity(spt, gpu_film, exhaustive),
+                             "note": "reference_walk = the oracle as bvh.rs / bbox.rs are written (the timed cpu_baseline); exhaustive = "
+                                     "every triangle tested, (t, instance, prim) tie rule - the answer the library's padded trees reproduce"}
+        if world == 1 and not args.no_secondary:
+            try:
+                out["other_configs"] = other_configs(spt, local_rank)
+            except Exception as e:   # the headline line must survive a failure of the extras
+                out["other_configs"] = {"error": repr(e)}
         print(json.dumps(out))
     if dist is not None:
         barrier()
-        if rank == 0 and film is not None:   # the assembled image: every pixel was written by exactly one rank
-            assert np.isfinite(film.film).all() and float(film.film.max()) > 0.0
+        f = films.get((args.height, args.width))
+        if rank == 0 and f is not None:   # the assembled image: every pixel was written by exactly one rank
+            assert np.isfinite(f.film).all() and float(f.film.max()) > 0.0
         barrier()
-        film.close()
+        for f in films.values():
+            f.close()
         dist.destroy_process_group()
+
+
+def other_configs(spt, device):
+    """BASELINE configs[3] (cfg4, 1024x1024 @ 512 spp) and one GPU's share of configs[4] (cfg5, shard 0 of 8 of 2048x2048 @ 512
+    spp): Msamples/s, per-kernel-class ms, and the dominant kernel's algorithmic bytes.  Scenes are generated from their
+    seeds (scenes_amd/make_scenes.py).  Outside the timed `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "scenes_amd"))
+    import make_scenes
+    gen = make_scenes.make_full()
+    res = {}
+    for key, scene_f, rend_f, w, h, shard_count, label in (
+            ("cfg4_materials_env", "cfg4_materials_env.json", "pt_random512.json", 1024, 1024, 1,
+             "BASELINE configs[3]: GGX conductor + rough / smooth glass + 1024x512 EXR env MIS, 1024x1024 @ 512 spp, whole image"),
+            ("cfg5_blob_medium_shard0of8", "cfg5_blob_medium.json", "pt_recurrence512.json", 2048, 2048, 8,
+             "BASELINE configs[4]: 998 k-triangle mesh + homogeneous medium, 2048x2048 @ 512 spp, ONE GPU's share (shard 0 of 8)")):
+        sc = spt.load_scene(os.path.join(gen, scene_f))
+        r = spt.load_renderer(os.path.join(gen, rend_f), seed=1)
+        cfg = spt.OutputConfig(w, h, None, "main")
+        kw = dict(device=device, shard_index=0, shard_count=shard_count, strip_rows=16, reuse_output=True)
+        r.render_shard(sc, cfg, **kw)                                  # warm-up (workspace allocation)
+        best = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r.render_shard(sc, cfg, **kw)
+            best = min(best, time.perf_counter() - t0)
+        st = r.last_stats
+        smp, seg_c, seg_s = st.samples, st.segments_closest, st.segments_shadow
+        ext, hits0, verts = seg_c - smp, st.primary_hits, st.path_vertices
+        r.render_shard(sc, cfg, profile=True, **kw)                    # per-class HIP-event times (one stream)
+        pst = r.last_stats
+        kms = {spt.KERNEL_NAMES[k]: float(pst.kernel_ms[k]) for k in range(spt.N_KERNELS) if pst.kernel_launches[k]}
+        # visit counters of the traversal kernels (separate counting instantiations, SPT_RENDER_COUNT_VISITS)
+        r.render_shard(sc, cfg, count_visits=True, **kw)
+        vis = r.last_stats
+        geo = vis.node_visits * S_NODE + vis.tri_tests * S_TRI + vis.instance_visits * S_INST
+        queues = {
+            "primary": hits0 * (S_PATH0 + S_HIT) + (st.live_samples or hits0) * S_RAD,
+            "shade_first": hits0 * (S_PATH0 + S_HIT + S_ATTR) + st.shadow_first * S_SHADOW + min(ext, hits0) * S_PATH,
+            "shade": (verts - hits0) * (S_PATH + S_HIT + S_ATTR) + (seg_s - st.shadow_first) * S_SHADOW + max(ext - hits0, 0) * S_PATH,
+            "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
+            "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
+        }
+        dom = max((k for k in kms if k in queues), key=lambda k: kms[k])
+        entry = {
+            "workload": label, "samples": int(smp), "ms": round(best * 1e3, 2), "Msamples_per_s": round(smp / best / 1e6, 1),
+            "Mrays_per_s": round((seg_c + seg_s) / best / 1e6, 1), "segments_per_sample": round((seg_c + seg_s) / smp, 3),
+            "kernel_ms": {k: round(v, 2) for k, v in kms.items()}, "dominant_kernel": dom,
+        }
+        traversal = {"primary", "shadow", "extend"}
+        if vis.node_visits:
+            segs = seg_c + seg_s
+            entry["visits"] = {"node_records_per_segment": round(vis.node_visits / segs, 2), "triangles_per_segment": round(vis.tri_tests / segs, 2),
+                               "instances_per_segment": round(vis.instance_visits / segs, 2), "geometry_bytes_per_segment": round(geo / segs, 1)}
+            # geometry bytes of one kernel class ~ its share of the ray segments (the counters are per render, not per class)
+            share = {"primary": smp / segs, "extend": ext / segs, "shadow": seg_s / segs}
+            alg = {k: queues[k] + (geo * share[k] if k in traversal else 0) for k in queues}
+        else:
+            entry["visits"] = None      # LDS-resident geometry: read once per workgroup, not per visit (SURVEY 8d)
+            alg = queues
+        gbs = alg[dom] / (kms[dom] * 1e-3) / 1e9
+        entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "alg_MB": round(alg[dom] / 1e6, 1), "ms": round(kms[dom], 2),
+                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "note": "algorithmic bytes = queue records + visit counters x record sizes (node %d, triangle %d, instance %d B); the "
+                                     "geometry of this scene is served by L2 / Infinity Cache, so this is a fetch rate, not HBM traffic"
+                                     % (S_NODE, S_TRI, S_INST)}
+        res[key] = entry
+        sc.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -429,14 +429,16 @@ class PathTracer:
 
     def render_shard(self, scene: Scene, config: OutputConfig, device: int = 0, shard_index: int = 0,
                      shard_count: int = 1, strip_rows: int = 16, samples_per_pass: int = 0,
-                     profile: bool = False, reuse_output: bool = False, film: Optional[np.ndarray] = None) -> np.ndarray:
+                     profile: bool = False, reuse_output: bool = False, film: Optional[np.ndarray] = None,
+                     count_visits: bool = False) -> np.ndarray:
         """Mean radiance of this shard's rows, shape (rows, width, 3) f32, via the HIP path.
         reuse_output=True returns a page-locked buffer owned by the device scene that the next call
-        with the same shape overwrites (no per-call allocation, DMA-speed copy-out)."""
+        with the same shape overwrites (no per-call allocation, DMA-speed copy-out).
+        count_visits=True runs the counting instantiations of the traversal kernels (last_stats.node_visits, ...)."""
         ds = scene.device_scene(device)
         cam = scene.get_camera(config.used_camera_name)
         p = self.params(config.width, config.height, shard_index, shard_count, strip_rows, samples_per_pass,
-                        RENDER_PROFILE if profile else 0)
+                        (RENDER_PROFILE if profile else 0) | (RENDER_COUNT_VISITS if count_visits else 0))
         rows = C.c_uint32()
         _check_hip(hip_lib().spt_shard_rows(C.byref(p), C.byref(rows)))
         if film is not None:

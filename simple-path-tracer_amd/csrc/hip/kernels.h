@@ -88,6 +88,7 @@ struct RenderCtx {
     int32_t cull_i0, cull_i1, cull_j0, cull_j1;
     uint32_t n_tiles, primary_chunks, chunk_samples;   // k_primary<., kChunked>: tiles of the shard, chunks per tile, samples per chunk
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
+    unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
 };
 
 SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -172,6 +173,17 @@ SPT_DEV void pixel_offset(const RenderCtx& rc, uint32_t pixel, uint32_t s, DRng&
     }
 }
 
+// kCount kernels: add this lane's visit counts to the render's totals (one atomic per wave and counter)
+SPT_DEV void flush_visits(const RenderCtx& rc, const LaneVisits& vc) {
+    uint32_t v[3] = {vc.nodes, vc.tris, vc.insts};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        unsigned long long t = v[k];
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane_id() == 0u && t) atomicAdd(rc.visits + k, t);
+    }
+}
+
 SPT_DEV uint32_t pack_meta(uint32_t depth, int32_t medium) { return depth | ((uint32_t)(medium + 1) << 8); }
 
 SPT_DEV void store_path(const PathQueue& q, uint32_t i, const DRay& ray, float last_pdf, f3 thr, uint32_t slot, f3 lsi,
@@ -198,9 +210,10 @@ SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % 
 // EVERY sample of a live pixel owns a radiance slot (first_slot = 0) and the film is only touched by k_resolve,
 // which adds the slots in sample order: the same additions in the same order as the register sum of the
 // un-chunked kernel (a miss adds exactly +0 or its environment term), so the film is bit-identical.
-template <bool kLds, bool kChunked = false>
+template <bool kLds, bool kChunked = false, bool kCount = false>
 __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     stage_geometry<kLds>(sc);
+    LaneVisits vc{0u, 0u, 0u};
     const uint32_t tile = kChunked ? blockIdx.x % rc.n_tiles : blockIdx.x, chunk = kChunked ? blockIdx.x / rc.n_tiles : 0u;
     const uint32_t tx = tile % rc.tiles_x, ty = tile / rc.tiles_x;
     const uint32_t i = tx * kTile + (threadIdx.x % kTile);
@@ -250,7 +263,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
         if (may_hit || has_env) ray.d = normalize(du);
         DHit h;
         h.inst = -1;
-        if (may_hit) h = trace_closest<kLds>(sc, ray, SPT_F32_MAX);
+        if (may_hit) h = trace_closest<kLds, kCount>(sc, ray, SPT_F32_MAX, &vc);
         const bool hit = valid && h.inst >= 0;
         const size_t ri = (size_t)s * rc.n_pixels + lp;
         if (valid && !hit) {
@@ -285,6 +298,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
             rc.hits.inst[slot] = h.inst;
         }
     }
+    if (kCount) flush_visits(rc, vc);
     if (kChunked) {
         if (valid && chunk == 0u) rc.first_slot[lp] = live ? 0u : rc.pass_samples;
     } else if (valid) {
@@ -659,12 +673,13 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool kLds>
+template <bool kLds, bool kCount = false>
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
     if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
     stage_geometry<kLds>(sc);
+    LaneVisits vc{0u, 0u, 0u};
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
     for (uint32_t i = (blockIdx.x / kShards) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -672,17 +687,19 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_
         float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx], c = rc.shadow.contrib_slot[idx];
         DRay r;
         r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-        if (!trace_any<kLds>(sc, r, b.w)) rad_add(rc, __float_as_uint(c.w), mk3(c));
+        if (!trace_any<kLds, kCount>(sc, r, b.w, &vc)) rad_add(rc, __float_as_uint(c.w), mk3(c));
     }
+    if (kCount) flush_visits(rc, vc);
 }
 
 // ---------------------------------------------------------------------------- extend
-template <bool kLds>
+template <bool kLds, bool kCount = false>
 __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
     if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
     stage_geometry<kLds>(sc);
+    LaneVisits vc{0u, 0u, 0u};
     uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
@@ -699,7 +716,7 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
             rs = rc.qb.rng[idx];
             DRay r;
             r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-            h = trace_closest<kLds>(sc, r, SPT_F32_MAX);
+            h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
             const uint32_t meta = __float_as_uint(d.w);
             const bool in_medium = (meta >> 8) != 0u;
             if (h.inst >= 0 || in_medium) {
@@ -720,6 +737,7 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
             rc.hits.inst[slot] = h.inst;
         }
     }
+    if (kCount) flush_visits(rc, vc);
 }
 
 // ---------------------------------------------------------------------------- persistent, refilling variants
@@ -752,6 +770,7 @@ SPT_DEV uint32_t wave_pull(bool want, uint32_t* cursor) {
     return want ? base + (uint32_t)__popcll(mask & lt) : 0xffffffffu;
 }
 
+template <bool kCount>
 __global__ void __launch_bounds__(256, 2) k_shadow_dyn(DScene sc, RenderCtx rc, uint32_t bounce) {
     stage_geometry<false>(sc);
     const uint32_t shard = blockIdx.x % kShards;
@@ -759,7 +778,8 @@ __global__ void __launch_bounds__(256, 2) k_shadow_dyn(DScene sc, RenderCtx rc, 
     uint32_t* cursor = q_count(rc.counts, bounce, Q_SHADOW_CURSOR, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     uint2 spill_mem[kSpillStack];
-    Walker<false, false> wk;
+    Walker<false, false, kCount> wk;
+    wk.vc = LaneVisits{0u, 0u, 0u};
     bool busy = false, drained = false;
     uint32_t idx = 0;
     while (true) {
@@ -788,8 +808,10 @@ __global__ void __launch_bounds__(256, 2) k_shadow_dyn(DScene sc, RenderCtx rc, 
             busy = false;
         }
     }
+    if (kCount) flush_visits(rc, wk.vc);
 }
 
+template <bool kCount>
 __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, uint32_t bounce) {
     stage_geometry<false>(sc);
     const uint32_t shard = blockIdx.x % kShards;
@@ -798,7 +820,8 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
     uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     uint2 spill_mem[kSpillStack];
-    Walker<false, true> wk;
+    Walker<false, true, kCount> wk;
+    wk.vc = LaneVisits{0u, 0u, 0u};
     bool busy = false, drained = false;
     uint32_t idx = 0;
     while (true) {
@@ -845,162 +868,5 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
             rc.hits.inst[slot] = wk.h.inst;
         }
     }
-}
-
-// ---------------------------------------------------------------------------- resolve
-__global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
-    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lp >= rc.n_pixels) return;
-    const uint32_t first = rc.first_slot[lp];
-    if (first >= rc.pass_samples) return;
-    const size_t plane = rc.rad_plane;
-    f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
-    // the additions are sequential (sample order = the reference's, film.rs:87), the loads are not: 8 samples
-    // (24 loads) in flight per lane, which matters when a narrow shard leaves few pixels to hide latency with
-    uint32_t s = first;
-    for (; s + 8u <= rc.pass_samples; s += 8u) {
-        float r[8], g[8], b[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
-            const size_t ri = (size_t)(s + k) * rc.n_pixels + lp;
-            r[k] = rc.rad[ri]; g[k] = rc.rad[plane + ri]; b[k] = rc.rad[2 * plane + ri];
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) sum = sum + mk3(r[k], g[k], b[k]);
-    }
-    for (; s < rc.pass_samples; ++s) {
-        const size_t ri = (size_t)s * rc.n_pixels + lp;
-        sum = sum + mk3(rc.rad[ri], rc.rad[plane + ri], rc.rad[2 * plane + ri]);  // film.rs:87
-    }
-    rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
-}
-
-// film.rs:91: color / weight_sum  (Color / f32 = Color * (1/f32))
-__global__ void __launch_bounds__(256) k_finish(RenderCtx rc, float* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rc.n_pixels * 3u) return;
-    out[i] = rc.film[i] * rc.spp_inv;
-}
-
-// ---------------------------------------------------------------------------- general box filter
-// BoxFilter::weight (src/filter/boxf.rs:27-33) of sample s of `pixel` seen from a pixel (di, dj) away: the film keeps
-// (offset - 0.5) per sample (pt.rs:278) and filter_pixel adds the pixel distance (film.rs:84-85).  The offsets are the
-// sampler's first draws of the sample's stream, so they are recomputed here instead of being stored.
-SPT_DEV float box_weight(const RenderCtx& rc, uint32_t pixel, uint32_t s, int32_t di, int32_t dj, float radius) {
-    DRng rng;
-    rng.s.state = 0ull;
-    if (rc.sampler != SPT_SAMPLER_RECURRENCE) rng.s = spt_rng_seed(rc.seed, pixel, s);
-    float ox, oy;
-    pixel_offset(rc, pixel, s, rng, &ox, &oy);
-    const float wx = (float)di + (ox - 0.5f), wy = (float)dj + (oy - 0.5f);
-    return (fabsf(wx) <= radius && fabsf(wy) <= radius) ? 1.0f : 0.0f;
-}
-
-// radius_int <= 0 (radius <= 0.5): the colour is the pixel's own in-order sum (rc.film), the weight sum counts the
-// samples whose offset lies inside the box (all of them at radius 0.5, which is k_finish).  radius_int < 0
-// (radius <= -0.5) leaves both loops of filter_pixel empty: 0 * (1 / 0).
-__global__ void __launch_bounds__(256) k_finish_box(RenderCtx rc, float* out, float radius, int32_t R) {
-    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lp >= rc.n_pixels) return;
-    f3 sum = mk3(0, 0, 0);
-    float wsum = 0.0f;
-    if (R == 0) {
-        const uint32_t row_local = lp / rc.width, col = lp - row_local * rc.width;
-        const uint32_t pixel = global_row(rc, row_local) * rc.width + col;
-        sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
-        for (uint32_t s = 0; s < rc.spp; ++s) wsum += box_weight(rc, pixel, s, 0, 0, radius);
-    }
-    const f3 c = sum * (1.0f / wsum);   // film.rs:91, Color / f32 = Color * (1 / f32) (color.rs:125-131)
-    out[3 * lp] = c.x; out[3 * lp + 1] = c.y; out[3 * lp + 2] = c.z;
-}
-
-// radius_int >= 1: Film::filter_pixel (film.rs:71-92) over the kept samples of a band of whole rows.  Rows j, then
-// columns i, then the samples of that pixel in the order they were added, one running colour sum (the colour is NOT
-// weighted - film.rs:87 adds sample.color as is - only weight_sum looks at the offsets).
-struct BoxJob {
-    const float* rad;               // 3 planes [c][sample][band pixel]
-    uint32_t band_base, band_rows;  // image rows held by the planes
-    uint32_t out_j0, out_rows;      // image rows to filter
-    float* out;                     // first pixel of row out_j0 in the packed output of the shard
-    int32_t R;
-    float radius;
-};
-__global__ void __launch_bounds__(256) k_filter_box(RenderCtx rc, BoxJob job) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= job.out_rows * rc.width) return;
-    const uint32_t row = idx / rc.width, x = idx - row * rc.width;
-    const int32_t y = (int32_t)(job.out_j0 + row);
-    const size_t n_band = (size_t)job.band_rows * rc.width, plane = n_band * rc.spp;
-    f3 sum = mk3(0, 0, 0);
-    float wsum = 0.0f;
-    for (int32_t dj = -job.R; dj <= job.R; ++dj) {
-        const int32_t jj = y + dj;
-        if (jj < 0 || jj >= (int32_t)rc.height) continue;
-        for (int32_t di = -job.R; di <= job.R; ++di) {
-            const int32_t ii = (int32_t)x + di;
-            if (ii < 0 || ii >= (int32_t)rc.width) continue;
-            const uint32_t pixel = (uint32_t)jj * rc.width + (uint32_t)ii;
-            const size_t lp = (size_t)((uint32_t)jj - job.band_base) * rc.width + (uint32_t)ii;
-            for (uint32_t s = 0; s < rc.spp; ++s) {
-                const size_t ri = (size_t)s * n_band + lp;
-                sum = sum + mk3(job.rad[ri], job.rad[plane + ri], job.rad[2 * plane + ri]);
-                wsum += box_weight(rc, pixel, s, di, dj, job.radius);
-            }
-        }
-    }
-    const f3 c = sum * (1.0f / wsum);
-    job.out[3 * (size_t)idx] = c.x; job.out[3 * (size_t)idx + 1] = c.y; job.out[3 * (size_t)idx + 2] = c.z;
-}
-
-// ---------------------------------------------------------------------------- test seams
-template <bool kLds>
-__global__ void __launch_bounds__(256) k_trace_closest(DScene sc, uint32_t n, const spt_ray* rays, spt_hit* hits) {
-    stage_geometry<kLds>(sc);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    DRay r;
-    r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
-    DHit h = trace_closest<kLds>(sc, r, rays[i].t_max);
-    const bool hit = h.inst >= 0;
-    hits[i].t = hit ? h.t : SPT_F32_MAX;
-    hits[i].instance = h.inst;
-    hits[i].prim = hit ? h.prim : -1;
-    hits[i].v = hit ? h.v : 0.0f;
-    hits[i].w = hit ? h.w : 0.0f;
-}
-template <bool kLds>
-__global__ void __launch_bounds__(256) k_trace_any(DScene sc, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
-    stage_geometry<kLds>(sc);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    DRay r;
-    r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
-    occluded[i] = trace_any<kLds>(sc, r, rays[i].t_max) ? 1 : 0;
-}
-
-__global__ void k_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float x = a[i], y = b[i], r;
-    switch (fn) {
-    case 0: r = spt_sin(x); break;
-    case 1: r = spt_cos(x); break;
-    case 2: r = spt_log(x); break;
-    case 3: r = spt_exp(x); break;
-    case 4: r = spt_acos(x); break;
-    case 5: r = spt_atan2(x, y); break;
-    case 6: r = spt_asin(x); break;
-    case 7: r = spt_round(x); break;
-    case 8: r = spt_floor(x); break;
-    case 9: r = spt_sqrt(x); break;
-    case 10: r = x / y; break;
-    case 11: r = spt_max(x, y); break;
-    case 12: r = spt_min(x, y); break;
-    case 13: r = spt_pow(x, y); break;
-    case 14: r = spt_log2(x); break;
-    case 15: r = spt_trunc(x); break;
-    case 16: r = spt_fract(x); break;
-    default: r = 0.0f; break;
-    }
-    out[i] = r;
+    if (kCount) flush_visits(rc, wk.vc);
 }

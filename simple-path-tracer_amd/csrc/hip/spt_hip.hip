@@ -15,7 +15,8 @@
 #include <string>
 #include <vector>
 
-#include "kernels.h"
+#include "kernel_list.h"   // the heavy kernel templates: declared here, compiled in inst_*.hip
+#include "film_kernels.h"
 
 namespace {
 
@@ -497,7 +498,7 @@ struct spt_scene {
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, out;
-    DeviceBuffer trace_in, trace_out;
+    DeviceBuffer trace_in, trace_out, visits;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
@@ -1115,6 +1116,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
 
         hipStream_t st = sc->stream;
         const bool profile = (p.flags & SPT_RENDER_PROFILE) != 0;
+        // visit counters: only the kernels that fetch their geometry from memory count (an LDS-resident scene is read once
+        // per workgroup whatever the rays do)
+        const bool count = (p.flags & SPT_RENDER_COUNT_VISITS) != 0 && !sc->lds_geo;
+        sc->visits.ensure(4 * sizeof(unsigned long long));
+        if (count) HIP_CHECK(hipMemsetAsync(sc->visits.p, 0, 4 * sizeof(unsigned long long), sc->stream));
         // per-kernel event timing needs one stream; so does a scene with an environment (see the bounce loop)
         const bool overlap = !profile && sc->d.env_w == 0u && std::getenv("SPT_NO_OVERLAP") == nullptr;
         const size_t lds = sc->lds_bytes;
@@ -1282,6 +1288,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
 
             rc.dyn_refill_below = dyn_refill_below;
             rc.dyn_steps = dyn_steps;
+            rc.visits = sc->visits.as<unsigned long long>();
             // tiles of this shard that intersect the screen-space bound (all of them with an environment)
             uint32_t active_tiles = pix_blocks;
             uint64_t live_pixels = n_pix;
@@ -1330,11 +1337,13 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 }
                 if (rc.primary_chunks > 1u || collect) {   // collect: every sample owns a slot, which is what the chunked kernel does
                     chunked_any = true;
-                    if (L) hipLaunchKernelGGL((k_primary<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
-                    else hipLaunchKernelGGL((k_primary<false, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    if (L) hipLaunchKernelGGL((k_primary<true, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (count) hipLaunchKernelGGL((k_primary<false, true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    else hipLaunchKernelGGL((k_primary<false, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                 } else {
-                    if (L) hipLaunchKernelGGL((k_primary<true, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
-                    else hipLaunchKernelGGL((k_primary<false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    if (L) hipLaunchKernelGGL((k_primary<true, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (count) hipLaunchKernelGGL((k_primary<false, false, true>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    else hipLaunchKernelGGL((k_primary<false, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                 }
                 end();
                 for (uint32_t b = 0; b < p.max_depth; ++b) {
@@ -1344,8 +1353,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         // (qa, hits) for even b and in (qb, hits_next) for odd b
                         RenderCtx rb = rc;
                         if (b & 1u) { std::swap(rb.qa, rb.qb); std::swap(rb.hits, rb.hits_next); }
-                        if (b == 0) hipLaunchKernelGGL((k_shade<0, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
-                        else hipLaunchKernelGGL((k_shade<0, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                        if (b == 0) hipLaunchKernelGGL((k_shade<0, true, true, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                        else hipLaunchKernelGGL((k_shade<0, false, true, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
                         end();
                         continue;
                     }
@@ -1353,11 +1362,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     const size_t shade_lds = sc->subsurface ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3>: traversal stack
 #define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
         if (tab) {                                                                                                                                 \
-            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
-            else hipLaunchKernelGGL((k_shade<FEAT, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);              \
+            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);  \
+            else hipLaunchKernelGGL((k_shade<FEAT, false, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
         } else {                                                                                                                                   \
-            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);               \
-            else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);                     \
+            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b); \
+            else hipLaunchKernelGGL((k_shade<FEAT, false, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);       \
         }
                     if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) }
                     else if (tab || !L) { SPT_LAUNCH_SHADE(3) }
@@ -1378,16 +1387,20 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
                     }
                     begin(SPT_K_SHADOW);
-                    if (L) hipLaunchKernelGGL(k_shadow<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                    else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                    else hipLaunchKernelGGL(k_shadow<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    else if (dyn_shadow && count) hipLaunchKernelGGL(k_shadow_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    else if (count) hipLaunchKernelGGL((k_shadow<false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
                     end();
                     if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
                     if (b + 1 < p.max_depth) {
                         begin(SPT_K_EXTEND);
-                        if (L) hipLaunchKernelGGL(k_extend<true>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else hipLaunchKernelGGL(k_extend<false>, dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else if (dyn_extend && count) hipLaunchKernelGGL(k_extend_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else if (count) hipLaunchKernelGGL((k_extend<false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        else hipLaunchKernelGGL((k_extend<false, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
                         end();
                     }
                     if (side) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_join, 0));
@@ -1470,9 +1483,15 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                                              rest_rows * (size_t)p.width * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
             }
         }
+        unsigned long long h_visits[4] = {0, 0, 0, 0};
+        if (count) HIP_CHECK(hipMemcpyAsync(h_visits, sc->visits.p, sizeof h_visits, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(ev_total1, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (stats) {
+            stats->node_visits = h_visits[0];
+            stats->tri_tests = h_visits[1];
+            stats->instance_visits = h_visits[2];
+            stats->node_bytes = h_visits[0] * 64ull;   // wide 2-ary and compressed 4-ary nodes are both 64-byte records
             stats->samples = samples_traced;
             stats->segments_closest = seg_closest;
             stats->segments_shadow = seg_shadow;

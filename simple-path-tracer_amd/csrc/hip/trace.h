@@ -74,6 +74,17 @@ struct DHit {
     float v, w;
 };
 
+// SPT_RENDER_COUNT_VISITS: what one lane's walks fetched (kCount instantiations only; a null pointer otherwise)
+struct LaneVisits {
+    uint32_t nodes, tris, insts;
+};
+template <bool kCount>
+SPT_DEV void count_node(LaneVisits* c) { if (kCount) ++c->nodes; }
+template <bool kCount>
+SPT_DEV void count_tri(LaneVisits* c) { if (kCount) ++c->tris; }
+template <bool kCount>
+SPT_DEV void count_inst(LaneVisits* c) { if (kCount) ++c->insts; }
+
 // per-lane stack in LDS: entry `level` of this lane
 extern __shared__ uint32_t spt_lds_stack[];
 SPT_DEV uint32_t& stack_at(uint32_t word) { return spt_lds_stack[word * blockDim.x + threadIdx.x]; }
@@ -320,9 +331,9 @@ SPT_DEV void node4_sort(Node4* n) {
 // Near-first walk of one wide-node tree.  `limit` is read on every test, so a closest-hit walk
 // (kClosest: cull with t0 <= limit, the tie rule) tightens as `leaf` lowers it; an any-hit walk culls
 // with t0 < limit.  leaf(first, count) returns true to stop the whole walk (any-hit found).
-template <bool kLds, bool kClosest, bool kN4, class LeafFn>
+template <bool kLds, bool kClosest, bool kN4, bool kCount, class LeafFn>
 SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o, f3 inv_d, float t_min, const float& limit,
-                       TStack& st, LeafFn leaf) {
+                       TStack& st, LaneVisits* vc, LeafFn leaf) {
     const uint32_t base = st.sp;
     uint32_t cur = root;
     while (true) {
@@ -330,6 +341,7 @@ SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o
             if (leaf(leaf_first(cur), leaf_count(cur))) { st.sp = base; return true; }
         } else if (kN4) {
             Node4 n;
+            count_node<kCount>(vc);
             node4_test<kLds>(sc, nodes_off + 4u * cur, o, inv_d, t_min, &n);
             node4_sort(&n);
             // farthest first onto the stack, nearest becomes `cur`
@@ -339,6 +351,7 @@ SPT_DEV bool walk_tree(const DScene& sc, uint32_t nodes_off, uint32_t root, f3 o
             if ((kClosest ? n.t0[0] <= limit : n.t0[0] < limit) && n.t0[0] < spt_inf()) { cur = n.ref[0]; continue; }
         } else {
             const uint32_t n = nodes_off + 4u * cur;
+            count_node<kCount>(vc);
             float4 a = geo_ld<kLds>(sc, n), b = geo_ld<kLds>(sc, n + 1u), c = geo_ld<kLds>(sc, n + 2u), d = geo_ld<kLds>(sc, n + 3u);
             float tl, tr;
             bool hl = slab_t0(a, b, o, inv_d, t_min, &tl);
@@ -380,9 +393,10 @@ SPT_DEV bool key_less(int32_t inst, int32_t prim, const DHit& h) {
 }
 
 // one instance against the current best hit
-template <bool kLds>
-SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, DHit& h, TStack& st) {
+template <bool kLds, bool kCount = false>
+SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, DHit& h, TStack& st, LaneVisits* vc = nullptr) {
     uint32_t prim_type, prim_id;
+    count_inst<kCount>(vc);
     DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
     if (prim_type == SPT_PRIM_SPHERE) {
         float mn, mx;
@@ -408,10 +422,11 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
     const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(sc, orr.d);
     if (!root_hit<true>(rlo, rhi, orr.o, inv_o, orr.t_min, h.t)) return;
-    walk_tree<kLds, true, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
+    walk_tree<kLds, true, !kLds, kCount>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, h.t, st, vc, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
             int32_t id;
+            count_tri<kCount>(vc);
             bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w, &id);
             if (ok && t > orr.t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, id, h)))) {  // triangle.rs:187
                 h.t = t; h.inst = (int32_t)inst; h.prim = id; h.v = v; h.w = w;
@@ -421,9 +436,10 @@ SPT_DEV void instance_closest(const DScene& sc, uint32_t inst, const DRay& ray, 
     });
 }
 
-template <bool kLds>
-SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, float t_max, TStack& st) {
+template <bool kLds, bool kCount = false>
+SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, float t_max, TStack& st, LaneVisits* vc = nullptr) {
     uint32_t prim_type, prim_id;
+    count_inst<kCount>(vc);
     DRay orr = to_object<kLds>(sc, inst, ray, &prim_type, &prim_id);
     if (prim_type == SPT_PRIM_SPHERE) {
         float mn, mx;
@@ -439,10 +455,11 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
     const uint32_t root = __float_as_uint(rlo.w);
     const f3 inv_o = recip3(sc, orr.d);
     if (!root_hit<false>(rlo, rhi, orr.o, inv_o, orr.t_min, t_max)) return false;
-    return walk_tree<kLds, false, !kLds>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
+    return walk_tree<kLds, false, !kLds, kCount>(sc, sc.o_blas, root, orr.o, inv_o, orr.t_min, t_max, st, vc, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i) {
             float t, v, w;
             int32_t id;
+            count_tri<kCount>(vc);
             if (tri_test_geo<kLds>(sc, i, orr, &t, &v, &w, &id) && t > orr.t_min && t < t_max) return true;
         }
         return false;
@@ -450,8 +467,8 @@ SPT_DEV bool instance_any(const DScene& sc, uint32_t inst, const DRay& ray, floa
 }
 
 // Closest hit of the scene aggregate: BvhAccel<Instance> / Group::intersect
-template <bool kLds>
-SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
+template <bool kLds, bool kCount = false>
+SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max, LaneVisits* vc = nullptr) {
     DHit h;
     h.t = t_max;
     h.inst = -1;
@@ -462,13 +479,13 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
     TStack st;
     st.spill = spill_mem;
     if (sc.aggregate == SPT_AGGREGATE_GROUP) {
-        for (uint32_t i = 0; i < sc.n_instances; ++i) instance_closest<kLds>(sc, i, ray, h, st);
+        for (uint32_t i = 0; i < sc.n_instances; ++i) instance_closest<kLds, kCount>(sc, i, ray, h, st, vc);
     } else if (sc.n_tlas_nodes > 0) {
         const f3 inv_w = recip3(sc, ray.d);
         const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
         if (root_hit<true>(tlo, thi, ray.o, inv_w, ray.t_min, h.t))
-        walk_tree<kLds, true, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, [&](uint32_t first, uint32_t count) {
-            for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds>(sc, tlas_instance<kLds>(sc, i), ray, h, st);
+        walk_tree<kLds, true, false, kCount>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, h.t, st, vc, [&](uint32_t first, uint32_t count) {
+            for (uint32_t i = first; i < first + count; ++i) instance_closest<kLds, kCount>(sc, tlas_instance<kLds>(sc, i), ray, h, st, vc);
             return false;
         });
     }
@@ -476,23 +493,23 @@ SPT_DEV DHit trace_closest(const DScene& sc, const DRay& ray, float t_max) {
 }
 
 // Any hit in (t_min, t_max): intersect_test of the aggregate
-template <bool kLds>
-SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
+template <bool kLds, bool kCount = false>
+SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max, LaneVisits* vc = nullptr) {
     uint2 spill_mem[kSpillStack];
     TStack st;
     st.spill = spill_mem;
     if (sc.aggregate == SPT_AGGREGATE_GROUP) {
         for (uint32_t i = 0; i < sc.n_instances; ++i)
-            if (instance_any<kLds>(sc, i, ray, t_max, st)) return true;
+            if (instance_any<kLds, kCount>(sc, i, ray, t_max, st, vc)) return true;
         return false;
     }
     if (sc.n_tlas_nodes == 0) return false;
     const f3 inv_w = recip3(sc, ray.d);
     const float4 tlo = make_float4(sc.tlas_lo[0], sc.tlas_lo[1], sc.tlas_lo[2], 0.0f), thi = make_float4(sc.tlas_hi[0], sc.tlas_hi[1], sc.tlas_hi[2], 0.0f);
     if (!root_hit<false>(tlo, thi, ray.o, inv_w, ray.t_min, t_max)) return false;
-    return walk_tree<kLds, false, false>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, [&](uint32_t first, uint32_t count) {
+    return walk_tree<kLds, false, false, kCount>(sc, sc.o_tlas, sc.tlas_root, ray.o, inv_w, ray.t_min, t_max, st, vc, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first; i < first + count; ++i)
-            if (instance_any<kLds>(sc, tlas_instance<kLds>(sc, i), ray, t_max, st)) return true;
+            if (instance_any<kLds, kCount>(sc, tlas_instance<kLds>(sc, i), ray, t_max, st, vc)) return true;
         return false;
     });
 }
@@ -503,8 +520,9 @@ SPT_DEV bool trace_any(const DScene& sc, const DRay& ray, float t_max) {
 // with the nested loops above a wave runs until its slowest lane is done (measured on the 1 M-triangle
 // scene: 16 % of the lanes active in the shadow kernel, 30 % in extend), whereas a stepping walker
 // lets a persistent wave hand a finished lane the next ray of the queue while the others continue.
-template <bool kLds, bool kClosest>
+template <bool kLds, bool kClosest, bool kCount = false>
 struct Walker {
+    LaneVisits vc;             // kCount only (dead otherwise)
     f3 o, d, inv_w;            // world ray
     float t_min;
     f3 oo, od, inv_o;          // ray in the space of the current instance
@@ -541,6 +559,7 @@ struct Walker {
     // descend into the children of wide node `node`; returns false if neither child is hit
     SPT_DEV bool enter(const DScene& sc, uint32_t nodes_off, f3 ro, f3 rinv) {
         const uint32_t n = nodes_off + 4u * cur;
+        count_node<kCount>(&vc);
         float4 a = geo_ld<kLds>(sc, n), b = geo_ld<kLds>(sc, n + 1u), c = geo_ld<kLds>(sc, n + 2u), e = geo_ld<kLds>(sc, n + 3u);
         float tl, tr;
         bool hl = slab_t0(a, b, ro, rinv, t_min, &tl);
@@ -561,6 +580,7 @@ struct Walker {
     // same for a compressed 4-wide BLAS node
     SPT_DEV bool enter4(const DScene& sc) {
         Node4 n;
+        count_node<kCount>(&vc);
         node4_test<kLds>(sc, sc.o_blas + 4u * cur, oo, inv_o, t_min, &n);
         node4_sort(&n);
 #pragma unroll
@@ -588,6 +608,7 @@ struct Walker {
                     DRay orr;
                     orr.o = oo; orr.d = od; orr.t_min = t_min;
                     int32_t id;
+                    count_tri<kCount>(&vc);
                     bool ok = tri_test_geo<kLds>(sc, i, orr, &t, &v, &w, &id);
                     if (kClosest) {
                         if (ok && t > t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, id, h)))) {
@@ -618,6 +639,7 @@ struct Walker {
         // phase 0: next instance of the current leaf, else pop the TLAS stack
         if (inst_next < inst_end) {
             inst = tlas_instance<kLds>(sc, inst_next++);   // slot -> instance (identity for a GROUP aggregate)
+            count_inst<kCount>(&vc);
             uint32_t prim_type, prim_id;
             DRay wr;
             wr.o = o; wr.d = d; wr.t_min = t_min;

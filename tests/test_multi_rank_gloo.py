@@ -80,3 +80,18 @@ def test_shard_rows_partition_every_layout():
     for h, world, strip in ((37, 3, 4), (1024, 8, 16), (5, 8, 16), (64, 2, 1)):
         seen = np.concatenate([spt.shard_rows(h, r, world, strip) for r in range(world)])
         assert sorted(seen.tolist()) == list(range(h))
+
+
+def test_bench_launches_its_own_ranks_when_typed_plainly():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) must start the two ranks itself: here, without a
+    GPU, each rank gets as far as the device check and says so - the parent did not exit with a launch-me-differently error."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(_util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if p.returncode == 0:      # a box with GPUs: rank 0 printed the line
+        assert '"n_gpus": 2' in p.stdout and '"scaling": "strong"' in p.stdout
+    else:
+        assert p.stderr.count("no GPU visible; the HIP path has no CPU fallback") >= 1, p.stderr[-2000:]
+        assert "WORLD_SIZE=" not in p.stderr
