@@ -393,7 +393,7 @@ def main():
         dist.destroy_process_group()
 
 
-def other_configs(spt, device):
+def other_configs(spt, device, only=""):
     """BASELINE configs[3] (cfg4, 1024x1024 @ 512 spp) and one GPU's share of configs[4] (cfg5, shard 0 of 8 of 2048x2048 @ 512
     spp): Msamples/s, per-kernel-class ms, and the dominant kernel's algorithmic bytes.  Scenes are generated from their
     seeds (scenes_amd/make_scenes.py).  Outside the timed `value`."""
@@ -406,6 +406,8 @@ def other_configs(spt, device):
              "BASELINE configs[3]: GGX conductor + rough / smooth glass + 1024x512 EXR env MIS, 1024x1024 @ 512 spp, whole image"),
             ("cfg5_blob_medium_shard0of8", "cfg5_blob_medium.json", "pt_recurrence512.json", 2048, 2048, 8,
              "BASELINE configs[4]: 998 k-triangle mesh + homogeneous medium, 2048x2048 @ 512 spp, ONE GPU's share (shard 0 of 8)")):
+        if only and not key.startswith(only):
+            continue
         sc = spt.load_scene(os.path.join(gen, scene_f))
         r = spt.load_renderer(os.path.join(gen, rend_f), seed=1)
         cfg = spt.OutputConfig(w, h, None, "main")
@@ -444,9 +446,14 @@ def other_configs(spt, device):
             segs = seg_c + seg_s
             entry["visits"] = {"node_records_per_segment": round(vis.node_visits / segs, 2), "triangles_per_segment": round(vis.tri_tests / segs, 2),
                                "instances_per_segment": round(vis.instance_visits / segs, 2), "geometry_bytes_per_segment": round(geo / segs, 1)}
-            # geometry bytes of one kernel class ~ its share of the ray segments (the counters are per render, not per class)
-            share = {"primary": smp / segs, "extend": ext / segs, "shadow": seg_s / segs}
-            alg = {k: queues[k] + (geo * share[k] if k in traversal else 0) for k in queues}
+            rays = {"primary": smp, "shadow": seg_s, "extend": ext}
+            geo_cls = {}
+            for ci, cname in enumerate(("primary", "shadow", "extend")):
+                cv = vis.class_visits[ci]
+                geo_cls[cname] = cv[0] * S_NODE + cv[1] * S_TRI + cv[2] * S_INST
+                entry["visits"][cname] = {"rays": int(rays[cname]), "nodes_per_ray": round(cv[0] / max(rays[cname], 1), 2),
+                                          "triangles_per_ray": round(cv[1] / max(rays[cname], 1), 2), "instances_per_ray": round(cv[2] / max(rays[cname], 1), 2)}
+            alg = {k: queues[k] + (geo_cls[k] if k in traversal else 0) for k in queues}
         else:
             entry["visits"] = None      # LDS-resident geometry: read once per workgroup, not per visit
             alg = queues

@@ -339,6 +339,7 @@ typedef struct spt_render_stats {
     uint64_t tri_tests;            /* triangle records fetched and tested                                            */
     uint64_t instance_visits;      /* instance records fetched (ray transformed into object space)                   */
     uint64_t node_bytes;           /* bytes of the node records above (record sizes differ between the node formats)  */
+    uint64_t class_visits[3][3];   /* the same three counters per kernel class: [primary, shadow, extend][node, triangle, instance] */
 } spt_render_stats;
 
 /* Closest-hit record: what BvhAccel/Group::intersect leave in `Intersection`

@@ -175,7 +175,8 @@ class RenderStats(C.Structure):
                 ("gpu_ms", C.c_double), ("kernel_ms", C.c_double * N_KERNELS),
                 ("kernel_launches", C.c_uint32 * N_KERNELS), ("primary_hits", C.c_uint64),
                 ("path_vertices", C.c_uint64), ("shadow_first", C.c_uint64), ("vertices_second", C.c_uint64), ("live_samples", C.c_uint64),
-                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("instance_visits", C.c_uint64), ("node_bytes", C.c_uint64)]
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("instance_visits", C.c_uint64), ("node_bytes", C.c_uint64),
+                ("class_visits", (C.c_uint64 * 3) * 3)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("instance", "<i4"), ("prim", "<i4"), ("v", "<f4"), ("w", "<f4")])

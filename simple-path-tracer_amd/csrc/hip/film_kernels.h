@@ -134,6 +134,42 @@ __global__ void __launch_bounds__(256) k_trace_any(DScene sc, uint32_t n, const 
     occluded[i] = trace_any<kLds>(sc, r, rays[i].t_max) ? 1 : 0;
 }
 
+// the same seams through the streaming walker (scenes that do not fit LDS): one ray per lane, no refill
+__global__ void __launch_bounds__(256) k_trace_closest_stream(DScene sc, uint32_t n, const spt_ray* rays, spt_hit* hits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint2 spill_mem[kSpillStack];
+    SWalker<true, false> wk;
+    wk.done = true;
+    wk.cur = kNoRef;
+    if (i < n) {
+        DRay r;
+        r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
+        wk.begin(sc, r, rays[i].t_max);
+    }
+    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem);
+    if (i >= n) return;
+    const bool hit = wk.h.inst >= 0;
+    hits[i].t = hit ? wk.h.t : SPT_F32_MAX;
+    hits[i].instance = wk.h.inst;
+    hits[i].prim = hit ? wk.h.prim : -1;
+    hits[i].v = hit ? wk.h.v : 0.0f;
+    hits[i].w = hit ? wk.h.w : 0.0f;
+}
+__global__ void __launch_bounds__(256) k_trace_any_stream(DScene sc, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint2 spill_mem[kSpillStack];
+    SWalker<false, false> wk;
+    wk.done = true;
+    wk.cur = kNoRef;
+    if (i < n) {
+        DRay r;
+        r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
+        wk.begin(sc, r, rays[i].t_max);
+    }
+    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem);
+    if (i < n) occluded[i] = wk.h.inst >= 0 ? 1 : 0;
+}
+
 __global__ void k_detmath(uint32_t fn, uint32_t n, const float* a, const float* b, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

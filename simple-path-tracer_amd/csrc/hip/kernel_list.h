@@ -34,6 +34,17 @@
     X((k_extend_dyn<false>), SPT_ARGS_BOUNCE)        \
     X((k_extend_dyn<true>), SPT_ARGS_BOUNCE)
 
+// streaming kernels (stream.h): k_shadow_stream / k_extend_stream <kCount>, k_primary_stream<kChunked, kCount>
+#define SPT_KERNELS_STREAM(X)                             \
+    X((k_shadow_stream<false>), SPT_ARGS_BOUNCE)          \
+    X((k_shadow_stream<true>), SPT_ARGS_BOUNCE)           \
+    X((k_extend_stream<false>), SPT_ARGS_BOUNCE)          \
+    X((k_extend_stream<true>), SPT_ARGS_BOUNCE)           \
+    X((k_primary_stream<false, false>), SPT_ARGS_PRIMARY) \
+    X((k_primary_stream<true, false>), SPT_ARGS_PRIMARY)  \
+    X((k_primary_stream<false, true>), SPT_ARGS_PRIMARY)  \
+    X((k_primary_stream<true, true>), SPT_ARGS_PRIMARY)
+
 // k_shade<kFeat, kFirst, kFused, kTab, kGeoLds>
 #define SPT_KERNELS_SHADE0(X)                                        \
     X((k_shade<0, true, true, true, true>), SPT_ARGS_BOUNCE)         \
@@ -65,6 +76,8 @@
 SPT_KERNELS_PRIMARY(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_RAYS)
 SPT_KERNELS_RAYS(SPT_DEFINE_KERNEL)
+#elif defined(SPT_INSTANTIATE_GROUP_STREAM)
+SPT_KERNELS_STREAM(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE0)
 SPT_KERNELS_SHADE0(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE1)
@@ -78,6 +91,7 @@ SPT_KERNELS_SHADE3B(SPT_DEFINE_KERNEL)
 #else
 SPT_KERNELS_PRIMARY(SPT_DECLARE_KERNEL)
 SPT_KERNELS_RAYS(SPT_DECLARE_KERNEL)
+SPT_KERNELS_STREAM(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE0(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE1(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE2(SPT_DECLARE_KERNEL)

@@ -30,6 +30,7 @@
 // for any shard layout / GPU count.
 #pragma once
 #include "shading.h"
+#include "stream.h"
 
 
 struct DCamera {
@@ -44,9 +45,11 @@ struct PathQueue {            // SoA path-state queue (72 B / entry)
     float4* lsi_meta;         // light_sampler_inputs.position, depth | (medium+1)<<8 (bits)
     uint2* rng;               // PCG32 state
 };
-struct HitQueue {             // closest-hit records aligned with a PathQueue (20 B / entry)
+struct HitQueue {             // closest-hit records = the input of the shade stage (24 B / entry)
     float4* t_v_w_prim;       // t, v, w, prim (bits)
-    int32_t* inst;
+    uint2* inst_src;          // instance (-1: an in-medium miss), index of the path's record in the PathQueue it was traced
+                              // from: the extend stage does not copy the 72-byte path record next to its hit, the shade
+                              // stage of the next bounce fetches it through this index
 };
 struct ShadowQueue {          // 48 B / entry
     float4* o_tmin;
@@ -88,6 +91,7 @@ struct RenderCtx {
     int32_t cull_i0, cull_i1, cull_j0, cull_j1;
     uint32_t n_tiles, primary_chunks, chunk_samples;   // k_primary<., kChunked>: tiles of the shard, chunks per tile, samples per chunk
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
+    uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
 };
 
@@ -174,13 +178,14 @@ SPT_DEV void pixel_offset(const RenderCtx& rc, uint32_t pixel, uint32_t s, DRng&
 }
 
 // kCount kernels: add this lane's visit counts to the render's totals (one atomic per wave and counter)
-SPT_DEV void flush_visits(const RenderCtx& rc, const LaneVisits& vc) {
+// cls: 0 primary, 1 shadow, 2 extension rays
+SPT_DEV void flush_visits(const RenderCtx& rc, const LaneVisits& vc, uint32_t cls) {
     uint32_t v[3] = {vc.nodes, vc.tris, vc.insts};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         unsigned long long t = v[k];
         for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-        if (lane_id() == 0u && t) atomicAdd(rc.visits + k, t);
+        if (lane_id() == 0u && t) atomicAdd(rc.visits + 3u * cls + k, t);
     }
 }
 
@@ -295,10 +300,10 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
             // rebuilds, so only (direction, slot) and the hit record travel: 36 B instead of 92 B per hit
             rc.qa.d_pdf[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float((uint32_t)ri));
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
-            rc.hits.inst[slot] = h.inst;
+            rc.hits.inst_src[slot] = make_uint2((uint32_t)h.inst, slot);
         }
     }
-    if (kCount) flush_visits(rc, vc);
+    if (kCount) flush_visits(rc, vc, 0u);
     if (kChunked) {
         if (valid && chunk == 0u) rc.first_slot[lp] = live ? 0u : rc.pass_samples;
     } else if (valid) {
@@ -354,15 +359,18 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
     // the queue record of the NEXT iteration is requested before this iteration's shading (and traversals), so
     // its HBM latency is hidden behind them (2 - 3 waves / SIMD cannot hide it otherwise)
     constexpr bool kPrefetch = true;                 // (hit, direction / slot, instance): 9 registers
-    constexpr bool kPrefetchPath = !kFirst && kSimple;   // + the rest of the 72-byte path record: 14 more (k_shade<1> would reach 260 VGPRs = 1 wave / SIMD)
+    // + the rest of the 72-byte path record: 14 more (k_shade<1> would reach 260 VGPRs = 1 wave / SIMD).  Fused kernels only:
+    // there the record sits at the hit's own index; un-fused it is behind the hit's source index (see HitQueue)
+    constexpr bool kPrefetchPath = !kFirst && kSimple && kFused;
     float4 pre_hv = make_float4(0, 0, 0, 0), pre_b = make_float4(0, 0, 0, 0);
     float4 pre_a = pre_hv, pre_c = pre_hv, pre_d = pre_hv;
     uint2 pre_rs = make_uint2(0u, 0u);
-    int32_t pre_inst = -1;
+    uint2 pre_is = make_uint2(0xffffffffu, 0u);
     const uint32_t i_first = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u);
     if (kPrefetch && i_first + lane_id() < n) {
         const uint32_t k = qbase + i_first + lane_id();
-        pre_hv = rc.hits.t_v_w_prim[k]; pre_b = rc.qa.d_pdf[k]; pre_inst = rc.hits.inst[k];
+        pre_hv = rc.hits.t_v_w_prim[k]; pre_is = rc.hits.inst_src[k];
+        if (kFirst || kFused) pre_b = rc.qa.d_pdf[k];
         if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
     }
     for (uint32_t i0 = i_first; i0 < n; i0 += stride) {
@@ -370,10 +378,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
         const uint32_t idx = qbase + i0 + lane_id();
         const float4 cur_hv = pre_hv, cur_b = pre_b, cur_a = pre_a, cur_c = pre_c, cur_d = pre_d;
         const uint2 cur_rs = pre_rs;
-        const int32_t cur_inst = pre_inst;
+        const uint2 cur_is = pre_is;
         if (kPrefetch && i0 + stride + lane_id() < n) {
             const uint32_t k = idx + stride;
-            pre_hv = rc.hits.t_v_w_prim[k]; pre_b = rc.qa.d_pdf[k]; pre_inst = rc.hits.inst[k];
+            pre_hv = rc.hits.t_v_w_prim[k]; pre_is = rc.hits.inst_src[k];
+            if (kFirst || kFused) pre_b = rc.qa.d_pdf[k];
             if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
         }
         bool want_shadow = false, want_ext = false;
@@ -418,11 +427,14 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                 depth = 0u;
                 medium = -1;
             } else {
-                const float4 b = cur_b;
+                // the path's record: at the hit's own index when this kernel's predecessor wrote both (fused), else where
+                // the shade stage of the previous bounce left it (the extend stage only recorded the index)
+                const uint32_t src = kFused ? idx : cur_is.y;
+                const float4 b = kFused ? cur_b : rc.qa.d_pdf[src];
                 float4 a, c, d;
                 uint2 rs;
                 if (kPrefetchPath) { a = cur_a; c = cur_c; d = cur_d; rs = cur_rs; }
-                else { a = rc.qa.o_tmin[idx]; c = rc.qa.thr_slot[idx]; d = rc.qa.lsi_meta[idx]; rs = rc.qa.rng[idx]; }
+                else { a = rc.qa.o_tmin[src]; c = rc.qa.thr_slot[src]; d = rc.qa.lsi_meta[src]; rs = rc.qa.rng[src]; }
                 ray.o = mk3(a); ray.t_min = a.w;
                 ray.d = mk3(b);
                 last_pdf = b.w;
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             }
             DHit h;
             h.t = hv.x; h.v = hv.y; h.w = hv.z; h.prim = __float_as_int(hv.w);
-            h.inst = kPrefetch ? cur_inst : rc.hits.inst[idx];
+            h.inst = (int32_t)cur_is.x;
             const bool does_hit = h.inst >= 0;
             bool alive = true;       // false: path ended without the RR / depth tail (`break`)
             bool scattered = false;  // a new ray was produced (tail applies)
@@ -654,7 +666,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             if (keep) {
                 store_path(rc.qb, ns, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
                 rc.hits_next.t_v_w_prim[ns] = make_float4(nh.t, nh.v, nh.w, __int_as_float(nh.prim));
-                rc.hits_next.inst[ns] = nh.inst;
+                rc.hits_next.inst_src[ns] = make_uint2((uint32_t)nh.inst, ns);
             }
             continue;
         }
@@ -689,7 +701,7 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_
         r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
         if (!trace_any<kLds, kCount>(sc, r, b.w, &vc)) rad_add(rc, __float_as_uint(c.w), mk3(c));
     }
-    if (kCount) flush_visits(rc, vc);
+    if (kCount) flush_visits(rc, vc, 1u);
 }
 
 // ---------------------------------------------------------------------------- extend
@@ -707,21 +719,19 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
         const bool active = i0 + lane_id() < n;
         const uint32_t idx = qbase + i0 + lane_id();
         bool keep = false;
-        float4 a, b, c, d;
-        uint2 rs;
         DHit h;
         h.inst = -1; h.t = SPT_F32_MAX; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
         if (active) {
-            a = rc.qb.o_tmin[idx]; b = rc.qb.d_pdf[idx]; c = rc.qb.thr_slot[idx]; d = rc.qb.lsi_meta[idx];
-            rs = rc.qb.rng[idx];
+            const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
+            const uint32_t meta = __float_as_uint(rc.qb.lsi_meta[idx].w);
             DRay r;
             r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
             h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
-            const uint32_t meta = __float_as_uint(d.w);
             const bool in_medium = (meta >> 8) != 0u;
             if (h.inst >= 0 || in_medium) {
                 keep = true;
             } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
+                const float4 c = rc.qb.thr_slot[idx];
                 f3 env;
                 float env_pdf;
                 env_strength_pdf(sc, r.d, &env, &env_pdf);
@@ -729,15 +739,14 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_
                 rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
             }
         }
+        // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
         uint32_t slot = qbase + wave_push(keep, next_count);
         if (keep) {
-            rc.qa.o_tmin[slot] = a; rc.qa.d_pdf[slot] = b; rc.qa.thr_slot[slot] = c; rc.qa.lsi_meta[slot] = d;
-            rc.qa.rng[slot] = rs;
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
-            rc.hits.inst[slot] = h.inst;
+            rc.hits.inst_src[slot] = make_uint2((uint32_t)h.inst, idx);
         }
     }
-    if (kCount) flush_visits(rc, vc);
+    if (kCount) flush_visits(rc, vc, 2u);
 }
 
 // ---------------------------------------------------------------------------- persistent, refilling variants
@@ -808,7 +817,7 @@ __global__ void __launch_bounds__(256, 2) k_shadow_dyn(DScene sc, RenderCtx rc, 
             busy = false;
         }
     }
-    if (kCount) flush_visits(rc, wk.vc);
+    if (kCount) flush_visits(rc, wk.vc, 1u);
 }
 
 template <bool kCount>
@@ -822,7 +831,7 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
     uint2 spill_mem[kSpillStack];
     Walker<false, true, kCount> wk;
     wk.vc = LaneVisits{0u, 0u, 0u};
-    bool busy = false, drained = false;
+    bool busy = false, drained = false, in_medium = false;
     uint32_t idx = 0;
     while (true) {
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
@@ -831,6 +840,7 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
             if (!busy && i < n) {
                 idx = qbase + i;
                 float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
+                in_medium = (__float_as_uint(rc.qb.lsi_meta[idx].w) >> 8) != 0u;
                 DRay r;
                 r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
                 wk.start(sc, r, SPT_F32_MAX, spill_mem);
@@ -843,30 +853,236 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
             if (busy && !wk.done) wk.step(sc);
         const bool retire = busy && wk.done;
         bool keep = false;
-        float4 a, b, c, d;
-        uint2 rs;
         if (retire) {
-            a = rc.qb.o_tmin[idx]; b = rc.qb.d_pdf[idx]; c = rc.qb.thr_slot[idx]; d = rc.qb.lsi_meta[idx];
-            rs = rc.qb.rng[idx];
-            const bool in_medium = (__float_as_uint(d.w) >> 8) != 0u;
             if (wk.h.inst >= 0 || in_medium) {
                 keep = true;
             } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
+                const float4 b = rc.qb.d_pdf[idx], c = rc.qb.thr_slot[idx];
                 f3 env;
                 float env_pdf;
                 env_strength_pdf(sc, mk3(b), &env, &env_pdf);
-                float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
+                const float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
                 rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
             }
             busy = false;
         }
-        uint32_t slot = qbase + wave_push(keep, next_count);
+        // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
+        const uint32_t slot = qbase + wave_push(keep, next_count);
         if (keep) {
-            rc.qa.o_tmin[slot] = a; rc.qa.d_pdf[slot] = b; rc.qa.thr_slot[slot] = c; rc.qa.lsi_meta[slot] = d;
-            rc.qa.rng[slot] = rs;
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
-            rc.hits.inst[slot] = wk.h.inst;
+            rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
         }
     }
-    if (kCount) flush_visits(rc, wk.vc);
+    if (kCount) flush_visits(rc, wk.vc, 2u);
+}
+
+// ---------------------------------------------------------------------------- streaming kernels (stream.h)
+// The large-scene counterparts of k_primary / k_shadow / k_extend: persistent waves of 64 SWalkers that refill
+// idle lanes (from the queue shard, or - primary - with the lane's next camera sample) between while-while rounds.
+// Per-ray arithmetic of every PRIMITIVE test is that of trace.h, so the films are bit-identical to the other kernels'.
+constexpr uint32_t kStreamGuard = 1u << 24;   // outer iterations a persistent wave may run
+
+template <bool kCount>
+__global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx rc, uint32_t bounce) {
+    const uint32_t shard = blockIdx.x % kShards;
+    const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
+    uint32_t* cursor = q_count(rc.counts, bounce, Q_SHADOW_CURSOR, shard);
+    const uint32_t qbase = shard * rc.shard_cap;
+    uint2 spill_mem[kSpillStack];
+    SWalker<false, kCount> wk;
+    wk.vc = LaneVisits{0u, 0u, 0u};
+    wk.done = true;
+    wk.cur = kNoRef;
+    bool busy = false, drained = false;
+    uint32_t idx = 0;
+    // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
+    for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
+        const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+        if (!drained && n_busy < rc.stream_refill_below) {
+            const uint32_t i = wave_pull(!busy, cursor);
+            if (!busy && i < n) {
+                idx = qbase + i;
+                const float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx];
+                DRay r;
+                r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+                wk.begin(sc, r, b.w);
+                busy = true;
+            }
+            // the cursor only grows: once any lane was refused the shard is empty for good
+            drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
+        }
+        if (__ballot(busy) == 0ull) break;
+        wk.run(sc, rc.stream_rounds, spill_mem);
+        if (busy && wk.done) {
+            if (wk.h.inst < 0) {  // not occluded
+                const float4 c = rc.shadow.contrib_slot[idx];
+                rad_add(rc, __float_as_uint(c.w), mk3(c));
+            }
+            busy = false;
+        }
+    }
+    if (kCount) flush_visits(rc, wk.vc, 1u);
+}
+
+template <bool kCount>
+__global__ void __launch_bounds__(256, 2) k_extend_stream(DScene sc, RenderCtx rc, uint32_t bounce) {
+    const uint32_t shard = blockIdx.x % kShards;
+    const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
+    uint32_t* cursor = q_count(rc.counts, bounce, Q_EXT_CURSOR, shard);
+    uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
+    const uint32_t qbase = shard * rc.shard_cap;
+    uint2 spill_mem[kSpillStack];
+    SWalker<true, kCount> wk;
+    wk.vc = LaneVisits{0u, 0u, 0u};
+    wk.done = true;
+    wk.cur = kNoRef;
+    bool busy = false, drained = false, in_medium = false;
+    uint32_t idx = 0;
+    // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
+    for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
+        const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+        if (!drained && n_busy < rc.stream_refill_below) {
+            const uint32_t i = wave_pull(!busy, cursor);
+            if (!busy && i < n) {
+                idx = qbase + i;
+                const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
+                in_medium = (__float_as_uint(rc.qb.lsi_meta[idx].w) >> 8) != 0u;
+                DRay r;
+                r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+                wk.begin(sc, r, SPT_F32_MAX);
+                busy = true;
+            }
+            drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
+        }
+        if (__ballot(busy) == 0ull) break;
+        wk.run(sc, rc.stream_rounds, spill_mem);
+        const bool retire = busy && wk.done;
+        bool keep = false;
+        if (retire) {
+            if (wk.h.inst >= 0 || in_medium) {
+                keep = true;
+            } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
+                const float4 b = rc.qb.d_pdf[idx], c = rc.qb.thr_slot[idx];
+                f3 env;
+                float env_pdf;
+                env_strength_pdf(sc, mk3(b), &env, &env_pdf);
+                const float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
+                rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
+            }
+            busy = false;
+        }
+        // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
+        const uint32_t slot = qbase + wave_push(keep, next_count);
+        if (keep) {
+            rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
+            rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
+        }
+    }
+    if (kCount) flush_visits(rc, wk.vc, 2u);
+}
+
+// k_primary for large scenes: a lane owns a pixel and walks its samples one after the other; a lane whose walk is done
+// retires the sample (hit record / environment term / zero slot, exactly as k_primary) and starts its next one while the
+// rest of the wave keeps walking.  Same tiles, chunks, slots and film semantics as k_primary<false, kChunked>.
+template <bool kChunked, bool kCount>
+__global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx rc) {
+    const uint32_t tile = kChunked ? blockIdx.x % rc.n_tiles : blockIdx.x, chunk = kChunked ? blockIdx.x / rc.n_tiles : 0u;
+    const uint32_t tx = tile % rc.tiles_x, ty = tile / rc.tiles_x;
+    const uint32_t i = tx * kTile + (threadIdx.x % kTile);
+    const uint32_t row_local = ty * kTile + (threadIdx.x / kTile);
+    const bool valid = (i < rc.width) && (row_local < rc.rows);
+    const uint32_t lp = valid ? row_local * rc.width + i : 0u;
+    const uint32_t j = global_row(rc, row_local);
+    const uint32_t pixel = j * rc.width + i;
+    const bool has_env = sc.env_w != 0u;
+    const bool lazy_rng = rc.sampler == SPT_SAMPLER_RECURRENCE;
+    const uint32_t shard = tile_shard(tx, ty);
+    f3 sum = mk3(0, 0, 0);
+    if (!kChunked && valid) sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+    uint32_t first = kChunked ? 0u : rc.pass_samples;
+    const size_t plane = rc.rad_plane;
+    uint32_t* hit_counter = q_count(rc.counts, 0, Q_HIT, shard);
+    const bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
+    const bool live = valid && (in_bounds || has_env);
+    const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
+    const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
+    uint2 spill_mem[kSpillStack];
+    SWalker<true, kCount> wk;
+    wk.vc = LaneVisits{0u, 0u, 0u};
+    wk.done = true;
+    wk.cur = kNoRef;
+    uint32_t s = s_begin;        // next sample to start
+    uint32_t s_cur = 0u;         // sample being walked / retired
+    bool busy = false;
+    f3 dir = mk3(0, 0, 0);
+    // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
+    for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
+        // start the next sample of every idle lane that has one (a sample that cannot hit anything retires at once)
+        if (!busy && s < s_end) {
+            s_cur = s++;
+            const uint32_t gs = rc.pass_first + s_cur;
+            DRng rng;
+            rng.s.state = 0ull;
+            if (!lazy_rng) rng.s = spt_rng_seed(rc.seed, pixel, gs);
+            float ox, oy;
+            pixel_offset(rc, pixel, gs, rng, &ox, &oy);
+            const float x = (((float)i + ox) * rc.width_inv - 0.5f) * rc.aspect;           // pt.rs:269
+            const float y = ((float)(rc.height - j - 1u) + oy) * rc.height_inv - 0.5f;       // pt.rs:270-271
+            const f3 du = (rc.cam.forward * rc.cam.half_cot + rc.cam.right * x) + rc.cam.up * y;
+            bool may_hit = in_bounds;
+            if (may_hit && rc.bs_valid && rc.bs_c > 0.0f) {
+                const float b = dot(du, rc.bs_oc);
+                may_hit = (b > 0.0f) && (b * b >= dot(du, du) * rc.bs_c);
+            }
+            dir = du;
+            if (may_hit || has_env) dir = normalize(du);
+            busy = true;
+            wk.done = true;
+            wk.cur = kNoRef;
+            wk.h.inst = -1;
+            if (may_hit) {
+                DRay ray;
+                ray.o = rc.cam.eye; ray.t_min = kTMinEps; ray.d = dir;
+                wk.begin(sc, ray, SPT_F32_MAX);
+            }
+        }
+        if (__ballot(busy) == 0ull) break;
+        wk.run(sc, rc.stream_rounds, spill_mem);
+        const bool retire = busy && wk.done;
+        const bool hit = retire && wk.h.inst >= 0;
+        const size_t ri = (size_t)s_cur * rc.n_pixels + lp;
+        if (retire && !hit) {
+            if (has_env) {  // pt.rs:98-110 at depth 0: weight 1
+                f3 env;
+                float env_pdf;
+                env_strength_pdf(sc, dir, &env, &env_pdf);
+                const f3 c = mk3(0, 0, 0) + (gray(1.0f) * env) * 1.0f;
+                if (first == rc.pass_samples) {
+                    sum = sum + c;
+                } else {
+                    rc.rad[ri] = c.x; rc.rad[plane + ri] = c.y; rc.rad[2 * plane + ri] = c.z;
+                }
+            } else if (first != rc.pass_samples) {
+                rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
+            }
+        }
+        if (hit) {
+            if (first == rc.pass_samples) first = s_cur;
+            rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
+        }
+        const uint32_t slot = shard * rc.shard_cap + wave_push(hit, hit_counter);
+        if (hit) {
+            rc.qa.d_pdf[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)ri));
+            rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
+            rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, slot);
+        }
+        if (retire) busy = false;
+    }
+    if (kCount) flush_visits(rc, wk.vc, 0u);
+    if (kChunked) {
+        if (valid && chunk == 0u) rc.first_slot[lp] = (in_bounds || has_env) ? 0u : rc.pass_samples;
+    } else if (valid) {
+        rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
+        rc.first_slot[lp] = first;
+    }
 }

@@ -495,6 +495,7 @@ struct spt_scene {
     DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, bezier, surfaces, materials, mediums, lights;
     DeviceBuffer light_props, light_u, light_k, env_px, env_uk, geo;
     bool lds_geo = false;   // traversal geometry small enough to live in LDS (k_*<true>)
+    bool swalk = false;     // the streaming walker's tables (stream.h) were built: k_*_stream serve the scene
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, out;
@@ -832,8 +833,8 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             // for a GROUP aggregate, the leaf order of the device-built tree otherwise
             std::vector<uint32_t> tlas_order(s.n_instances);
             for (uint32_t i = 0; i < s.n_instances; ++i) tlas_order[i] = i;
+            std::vector<spt_bvh_node> own_tlas;
             if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) {
-                std::vector<spt_bvh_node> own_tlas;
                 if (own_bvh && s.n_instances) {
                     build_sah_tlas(s.instances, s.n_instances, own_tlas, tlas_order);   // boxes padded by the builder
                     tlas_depth = bvh_depth(own_tlas.data(), (uint32_t)own_tlas.size(), 0, s.n_instances, "device tlas");
@@ -871,6 +872,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 blob.clear();
                 std::vector<float4> wblas;
                 std::vector<float4> mesh_rec((size_t)s.n_meshes * 2, make_float4(0, 0, 0, 0));   // (root.lo, root ref) (root.hi, -)
+                uint32_t max_blas_need = 0;
                 for (uint32_t i = 0; i < s.n_meshes; ++i) {
                     const uint32_t mesh_root = own_bvh ? own_roots[i] : s.meshes[i].root;
                     const spt_bvh_node& rn = blas_src[mesh_root];
@@ -878,6 +880,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                     if (n4) {
                         uint32_t need = 0;
                         root_ref = build_n4(blas_src, mesh_root, wblas, &need, "blas");
+                        max_blas_need = std::max(max_blas_need, need);
                         if (tlas_depth + need + 2 > kLdsStack + kSpillStack)
                             fail(SPT_ERR_UNSUPPORTED, "4-wide BVH needs more than the traversal stack (48 entries)");
                     } else {
@@ -889,6 +892,48 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                     mesh_rec[2 * i] = make_float4(rn.bmin[0], rn.bmin[1], rn.bmin[2], rf);
                     mesh_rec[2 * i + 1] = make_float4(rn.bmax[0], rn.bmax[1], rn.bmax[2], 0.0f);
                 }
+                // streaming walker (stream.h): a 4-wide TLAS behind the BLAS nodes (refs of both levels index one array) and
+                // 96-byte instance entry records in its leaf order.  Its boxes only cull (quantised outward, relaxed
+                // test), so one tree serves both BVH modes and a GROUP aggregate alike.
+                sc->swalk = false;
+                d.s_root = 0u;
+                std::vector<float4> sinst;
+                if (n4 && s.n_instances) {
+                    const size_t blas_f4 = wblas.size();
+                    try {
+                        std::vector<spt_bvh_node> group_tlas;
+                        std::vector<uint32_t> s_order = tlas_order;
+                        const spt_bvh_node* src = nullptr;
+                        if (s.aggregate == SPT_AGGREGATE_BVH && s.n_tlas_nodes) {
+                            src = own_tlas.empty() ? s.tlas_nodes : own_tlas.data();
+                        } else {
+                            build_sah_tlas(s.instances, s.n_instances, group_tlas, s_order);
+                            src = group_tlas.data();
+                            for (int k = 0; k < 3; ++k) { d.tlas_lo[k] = src[0].bmin[k]; d.tlas_hi[k] = src[0].bmax[k]; }
+                        }
+                        uint32_t need_t = 0;
+                        d.s_root = build_n4(src, 0, wblas, &need_t, "tlas");
+                        // + 1: a TLAS leaf of several instances keeps its remaining instances as one extra entry
+                        if (need_t + max_blas_need + 3 > kLdsStack + kSpillStack) fail(SPT_ERR_UNSUPPORTED, "4-wide TLAS + BLAS need more than the traversal stack");
+                        sinst.assign((size_t)s.n_instances * 6, make_float4(0, 0, 0, 0));
+                        auto as_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+                        for (uint32_t slot = 0; slot < s.n_instances; ++slot) {
+                            const uint32_t ii = s_order[slot];
+                            const spt_instance& in = s.instances[ii];
+                            float4* r = &sinst[(size_t)slot * 6];
+                            std::memcpy(r, in.inv, 48);
+                            r[3] = make_float4(as_f(ii), as_f(in.prim_type), as_f(in.prim_id), 0.0f);
+                            if (in.prim_type == SPT_PRIM_MESH) { r[4] = mesh_rec[2 * in.prim_id]; r[5] = mesh_rec[2 * in.prim_id + 1]; }
+                            else if (in.prim_type == SPT_PRIM_SPHERE) { const spt_sphere& sp = s.spheres[in.prim_id]; r[4] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius); }
+                        }
+                        sc->swalk = std::getenv("SPT_NO_STREAM") == nullptr;
+                    } catch (const AbiError&) {
+                        wblas.resize(blas_f4);   // e.g. an instance box too large to quantise: the walkers of trace.h serve the scene
+                        sinst.clear();
+                        sc->swalk = false;
+                    }
+                }
+                d.o_sinst = append(sinst.data(), sinst.size() * 16);
                 d.o_tlas = append(wtlas.data(), wtlas.size() * 16);
                 d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
                 d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
@@ -1119,8 +1164,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         // visit counters: only the kernels that fetch their geometry from memory count (an LDS-resident scene is read once
         // per workgroup whatever the rays do)
         const bool count = (p.flags & SPT_RENDER_COUNT_VISITS) != 0 && !sc->lds_geo;
-        sc->visits.ensure(4 * sizeof(unsigned long long));
-        if (count) HIP_CHECK(hipMemsetAsync(sc->visits.p, 0, 4 * sizeof(unsigned long long), sc->stream));
+        sc->visits.ensure(12 * sizeof(unsigned long long));
+        if (count) HIP_CHECK(hipMemsetAsync(sc->visits.p, 0, 12 * sizeof(unsigned long long), sc->stream));
         // per-kernel event timing needs one stream; so does a scene with an environment (see the bounce loop)
         const bool overlap = !profile && sc->d.env_w == 0u && std::getenv("SPT_NO_OVERLAP") == nullptr;
         const size_t lds = sc->lds_bytes;
@@ -1195,13 +1240,13 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             sc->qa[4].ensure(cap * 8);
             sc->qb[4].ensure(cap * 8);
             sc->hit_f4.ensure(cap * 16);
-            sc->hit_inst.ensure(cap * 4);
+            sc->hit_inst.ensure(cap * 8);
             // see k_shade<.., kFused>.  Only the lean k_shade<0> variant gains: with the general kernel's 220+ VGPRs
             // the two traversals run at 2 waves / SIMD and cfg4 is faster un-fused (4.30 vs 4.00 Gsamples/s, measured)
             const bool fused = sc->fused && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
             if (fused) {
                 sc->hit_f4_next.ensure(cap * 16);
-                sc->hit_inst_next.ensure(cap * 4);
+                sc->hit_inst_next.ensure(cap * 8);
             }
             for (int k = 0; k < 3; ++k) sc->sh[k].ensure(cap * 16);
             const size_t counts_words = (size_t)(p.max_depth + 1) * Q_KINDS * kShards * 32;
@@ -1227,8 +1272,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.tiles_x = tiles_x;
             rc.qa = PathQueue{sc->qa[0].as<float4>(), sc->qa[1].as<float4>(), sc->qa[2].as<float4>(), sc->qa[3].as<float4>(), sc->qa[4].as<uint2>()};
             rc.qb = PathQueue{sc->qb[0].as<float4>(), sc->qb[1].as<float4>(), sc->qb[2].as<float4>(), sc->qb[3].as<float4>(), sc->qb[4].as<uint2>()};
-            rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<int32_t>()};
-            rc.hits_next = HitQueue{sc->hit_f4_next.as<float4>(), sc->hit_inst_next.as<int32_t>()};
+            rc.hits = HitQueue{sc->hit_f4.as<float4>(), sc->hit_inst.as<uint2>()};
+            rc.hits_next = HitQueue{sc->hit_f4_next.as<float4>(), sc->hit_inst_next.as<uint2>()};
             rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
             rc.counts = sc->counts.as<uint32_t>();
             rc.shard_cap = (uint32_t)shard_cap64;
@@ -1288,6 +1333,10 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
 
             rc.dyn_refill_below = dyn_refill_below;
             rc.dyn_steps = dyn_steps;
+            // rays of a path tracer are short (cfg5: ~4 node + ~2 triangle + ~1 instance records per segment = 2 - 3 rounds):
+            // a finished lane that waits several rounds for its wave costs more than the refill check
+            rc.stream_rounds = std::max(1u, std::min(255u, env_u32("SPT_STREAM_ROUNDS", 1u))) | (env_u32("SPT_STREAM_IFIF", 0u) ? 0x100u : 0u);
+            rc.stream_refill_below = env_u32("SPT_STREAM_REFILL", 40u);
             rc.visits = sc->visits.as<unsigned long long>();
             // tiles of this shard that intersect the screen-space bound (all of them with an environment)
             uint32_t active_tiles = pix_blocks;
@@ -1335,13 +1384,20 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     rc.chunk_samples = (rc.pass_samples + want - 1u) / want;
                     rc.primary_chunks = (rc.pass_samples + rc.chunk_samples - 1u) / rc.chunk_samples;
                 }
+                const bool stream = sc->swalk && !L;
+                const uint32_t stream_mask = env_u32("SPT_STREAM_MASK", 7u);   // A/B per kernel class: 1 primary, 2 shadow, 4 extend
+                const bool stream_p = stream && (stream_mask & 1u), stream_s = stream && (stream_mask & 2u), stream_e = stream && (stream_mask & 4u);
                 if (rc.primary_chunks > 1u || collect) {   // collect: every sample owns a slot, which is what the chunked kernel does
                     chunked_any = true;
-                    if (L) hipLaunchKernelGGL((k_primary<true, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    if (stream_p && count) hipLaunchKernelGGL((k_primary_stream<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (stream_p) hipLaunchKernelGGL((k_primary_stream<true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (L) hipLaunchKernelGGL((k_primary<true, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (count) hipLaunchKernelGGL((k_primary<false, true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else hipLaunchKernelGGL((k_primary<false, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                 } else {
-                    if (L) hipLaunchKernelGGL((k_primary<true, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    if (stream_p && count) hipLaunchKernelGGL((k_primary_stream<false, true>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (stream_p) hipLaunchKernelGGL((k_primary_stream<false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (L) hipLaunchKernelGGL((k_primary<true, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (count) hipLaunchKernelGGL((k_primary<false, false, true>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                     else hipLaunchKernelGGL((k_primary<false, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                 }
@@ -1358,21 +1414,26 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         end();
                         continue;
                     }
+                    // un-fused: the shade stage of bounce b reads the path records its predecessor wrote (ru.qa) through the
+                    // hits' source indices and writes the next ones to ru.qb, which the extend stage traces: the two path
+                    // queues swap roles every bounce, the hit queue is one buffer
+                    RenderCtx ru = rc;
+                    if (b & 1u) std::swap(ru.qa, ru.qb);
                     const bool tab = sc->lds_tables && std::getenv("SPT_NO_LDS_TABLES") == nullptr;   // shading tables from LDS (tab_ld)
                     const size_t shade_lds = sc->subsurface ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3>: traversal stack
 #define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
         if (tab) {                                                                                                                                 \
-            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);  \
-            else hipLaunchKernelGGL((k_shade<FEAT, false, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);        \
+            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);  \
+            else hipLaunchKernelGGL((k_shade<FEAT, false, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);        \
         } else {                                                                                                                                   \
-            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b); \
-            else hipLaunchKernelGGL((k_shade<FEAT, false, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, rc, b);       \
+            if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, ru, b); \
+            else hipLaunchKernelGGL((k_shade<FEAT, false, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, ru, b);       \
         }
                     if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) }
                     else if (tab || !L) { SPT_LAUNCH_SHADE(3) }
                     else {   // geometry in LDS, tables not: the probe still walks the LDS copy (k_shade's kGeoLds)
-                        if (b == 0) hipLaunchKernelGGL((k_shade<3, true, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else hipLaunchKernelGGL((k_shade<3, false, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        if (b == 0) hipLaunchKernelGGL((k_shade<3, true, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else hipLaunchKernelGGL((k_shade<3, false, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                     }
 #undef SPT_LAUNCH_SHADE
                     end();
@@ -1387,20 +1448,24 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
                     }
                     begin(SPT_K_SHADOW);
-                    if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                    else if (dyn_shadow && count) hipLaunchKernelGGL(k_shadow_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                    else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                    else if (count) hipLaunchKernelGGL((k_shadow<false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
-                    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, rc, b);
+                    if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else if (stream_s) hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else if (dyn_shadow && count) hipLaunchKernelGGL(k_shadow_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else if (count) hipLaunchKernelGGL((k_shadow<false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     end();
                     if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
                     if (b + 1 < p.max_depth) {
                         begin(SPT_K_EXTEND);
-                        if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else if (dyn_extend && count) hipLaunchKernelGGL(k_extend_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else if (count) hipLaunchKernelGGL((k_extend<false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
-                        else hipLaunchKernelGGL((k_extend<false, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rc, b);
+                        if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else if (stream_e) hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else if (dyn_extend && count) hipLaunchKernelGGL(k_extend_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else if (count) hipLaunchKernelGGL((k_extend<false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else hipLaunchKernelGGL((k_extend<false, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         end();
                     }
                     if (side) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_join, 0));
@@ -1483,15 +1548,17 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                                              rest_rows * (size_t)p.width * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
             }
         }
-        unsigned long long h_visits[4] = {0, 0, 0, 0};
+        unsigned long long h_visits[12] = {};
         if (count) HIP_CHECK(hipMemcpyAsync(h_visits, sc->visits.p, sizeof h_visits, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(ev_total1, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (stats) {
-            stats->node_visits = h_visits[0];
-            stats->tri_tests = h_visits[1];
-            stats->instance_visits = h_visits[2];
-            stats->node_bytes = h_visits[0] * 64ull;   // wide 2-ary and compressed 4-ary nodes are both 64-byte records
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) stats->class_visits[c][k] = h_visits[3 * c + k];
+            stats->node_visits = h_visits[0] + h_visits[3] + h_visits[6];
+            stats->tri_tests = h_visits[1] + h_visits[4] + h_visits[7];
+            stats->instance_visits = h_visits[2] + h_visits[5] + h_visits[8];
+            stats->node_bytes = stats->node_visits * 64ull;   // wide 2-ary and compressed 4-ary nodes are both 64-byte records
             stats->samples = samples_traced;
             stats->segments_closest = seg_closest;
             stats->segments_shadow = seg_shadow;
@@ -1503,11 +1570,13 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_total0, ev_total1));
             stats->gpu_ms = ms;
+            const bool debug_spans = std::getenv("SPT_DEBUG_SPANS") != nullptr;   // per-launch HIP-event times (profile mode)
             for (auto& sp : spans) {
                 float k = 0.0f;
                 HIP_CHECK(hipEventElapsedTime(&k, sc->events[sp.e0], sc->events[sp.e0 + 1]));
                 stats->kernel_ms[sp.cls] += k;
                 stats->kernel_launches[sp.cls] += 1;
+                if (debug_spans) std::fprintf(stderr, "[spt] span class %d: %.3f ms\n", sp.cls, k);
             }
         }
         return SPT_OK;
@@ -1539,7 +1608,10 @@ static spt_status trace_common(const spt_scene* scene_c, uint32_t n, const spt_r
         HIP_CHECK(hipMemcpyAsync(sc->trace_in.p, rays, (size_t)n * sizeof(spt_ray), hipMemcpyHostToDevice, st));
         const size_t lds = sc->lds_bytes;
         dim3 grid((n + kBlock - 1) / kBlock);
-        if (closest) {
+        if (sc->swalk && !sc->lds_geo) {
+            if (closest) hipLaunchKernelGGL(k_trace_closest_stream, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
+            else hipLaunchKernelGGL(k_trace_any_stream, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<uint8_t>());
+        } else if (closest) {
             if (sc->lds_geo) hipLaunchKernelGGL(k_trace_closest<true>, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
             else hipLaunchKernelGGL(k_trace_closest<false>, grid, dim3(kBlock), lds, st, sc->d, n, sc->trace_in.as<spt_ray>(), sc->trace_out.as<spt_hit>());
         } else {

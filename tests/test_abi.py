@@ -117,7 +117,7 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     # header, python mirror and the struct tail added with v9 agree
     hdr = open(os.path.join(_util.ROOT, "include", "spt_abi.h")).read()
     assert "#define SPT_ABI_VERSION %d" % spt.SPT_ABI_VERSION in hdr
-    assert spt.RenderStats.node_bytes.offset + 8 == C.sizeof(spt.RenderStats)
+    assert spt.RenderStats.class_visits.offset + 72 == C.sizeof(spt.RenderStats)
     assert spt.RenderParams.stats_size.offset + 4 == C.sizeof(spt.RenderParams)
     # the CLI checks the version of the library it found before doing anything else
     src = open(os.path.join(_util.PKG_DIR, "csrc", "cli", "main.cpp")).read()
