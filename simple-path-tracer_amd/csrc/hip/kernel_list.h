@@ -72,10 +72,20 @@
     X((k_shade<3, true, false, false, true>), SPT_ARGS_BOUNCE)       \
     X((k_shade<3, false, false, false, true>), SPT_ARGS_BOUNCE)
 
+// kind-sorted traversal (wst.h): k_trace_wst<Policy, kCount>
+#define SPT_ARGS_WST (DScene, RenderCtx, uint32_t, uint2*)
+#define SPT_KERNELS_WST(X)                              \
+    X((k_trace_wst<WstExtend, false>), SPT_ARGS_WST)    \
+    X((k_trace_wst<WstExtend, true>), SPT_ARGS_WST)     \
+    X((k_trace_wst<WstShadow, false>), SPT_ARGS_WST)    \
+    X((k_trace_wst<WstShadow, true>), SPT_ARGS_WST)
+
 #if defined(SPT_INSTANTIATE_GROUP_PRIMARY)
 SPT_KERNELS_PRIMARY(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_RAYS)
 SPT_KERNELS_RAYS(SPT_DEFINE_KERNEL)
+#elif defined(SPT_INSTANTIATE_GROUP_WST)
+SPT_KERNELS_WST(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_STREAM)
 SPT_KERNELS_STREAM(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE0)
@@ -92,6 +102,7 @@ SPT_KERNELS_SHADE3B(SPT_DEFINE_KERNEL)
 SPT_KERNELS_PRIMARY(SPT_DECLARE_KERNEL)
 SPT_KERNELS_RAYS(SPT_DECLARE_KERNEL)
 SPT_KERNELS_STREAM(SPT_DECLARE_KERNEL)
+SPT_KERNELS_WST(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE0(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE1(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE2(SPT_DECLARE_KERNEL)

@@ -1086,3 +1086,5 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
         rc.first_slot[lp] = first;
     }
 }
+
+#include "wst.h"   // kind-sorted traversal (uses the queue / context definitions above)

@@ -499,7 +499,7 @@ struct spt_scene {
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, out;
-    DeviceBuffer trace_in, trace_out, visits;
+    DeviceBuffer trace_in, trace_out, visits, wst_ovf;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
@@ -1335,7 +1335,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.dyn_steps = dyn_steps;
             // rays of a path tracer are short (cfg5: ~4 node + ~2 triangle + ~1 instance records per segment = 2 - 3 rounds):
             // a finished lane that waits several rounds for its wave costs more than the refill check
-            rc.stream_rounds = std::max(1u, std::min(255u, env_u32("SPT_STREAM_ROUNDS", 1u))) | (env_u32("SPT_STREAM_IFIF", 0u) ? 0x100u : 0u);
+            // if-if with 4 rounds per check: 87.4 ms; 8 rounds 95.2; while-while (SPT_STREAM_IFIF=0) 100 - 121 ms
+            rc.stream_rounds = std::max(1u, std::min(255u, env_u32("SPT_STREAM_ROUNDS", 4u))) | (env_u32("SPT_STREAM_IFIF", 1u) ? 0x100u : 0u);
             rc.stream_refill_below = env_u32("SPT_STREAM_REFILL", 40u);
             rc.visits = sc->visits.as<unsigned long long>();
             // tiles of this shard that intersect the screen-space bound (all of them with an environment)
@@ -1385,8 +1386,16 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     rc.primary_chunks = (rc.pass_samples + rc.chunk_samples - 1u) / rc.chunk_samples;
                 }
                 const bool stream = sc->swalk && !L;
-                const uint32_t stream_mask = env_u32("SPT_STREAM_MASK", 7u);   // A/B per kernel class: 1 primary, 2 shadow, 4 extend
+                // which kernel classes the streaming walker serves (1 primary, 2 shadow, 4 extend).  Measured on cfg5, one box
+                // (gpurun_out r2j): extension rays 93.5 ms refilling state machine -> 87.4 ms streaming if-if; primary rays
+                // 8.8 -> 12.4 ms and shadow rays 9.8 -> 11.3 ms (coherent / short walks: the state machine's tighter loop wins)
+                const uint32_t stream_mask = env_u32("SPT_STREAM_MASK", 4u);
                 const bool stream_p = stream && (stream_mask & 1u), stream_s = stream && (stream_mask & 2u), stream_e = stream && (stream_mask & 4u);
+                // kind-sorted traversal (wst.h) for the shadow / extension rays: 1 shadow, 2 extend
+                // (opt-in experiment, see DESIGN.md: its barrier-synchronous rounds are latency-starved - 180 - 215 ms vs 94)
+                const uint32_t wst_mask = stream ? env_u32("SPT_WST_MASK", 0u) : 0u;
+                const uint32_t wst_grid = kShards * kWstBlocksPerShard;
+                if (wst_mask) sc->wst_ovf.ensure((size_t)wst_grid * kWstRays * kSpillStack * sizeof(uint2));   // per slot: the levels beyond kWstStack (fewer than kSpillStack)
                 if (rc.primary_chunks > 1u || collect) {   // collect: every sample owns a slot, which is what the chunked kernel does
                     chunked_any = true;
                     if (stream_p && count) hipLaunchKernelGGL((k_primary_stream<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
@@ -1448,7 +1457,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
                     }
                     begin(SPT_K_SHADOW);
-                    if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    if ((wst_mask & 1u) && count) hipLaunchKernelGGL((k_trace_wst<WstShadow, true>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, ss, sc->d, ru, b, sc->wst_ovf.as<uint2>());
+                    else if (wst_mask & 1u) hipLaunchKernelGGL((k_trace_wst<WstShadow, false>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, ss, sc->d, ru, b, sc->wst_ovf.as<uint2>());
+                    else if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (stream_s) hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (dyn_shadow && count) hipLaunchKernelGGL(k_shadow_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
@@ -1459,7 +1470,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
                     if (b + 1 < p.max_depth) {
                         begin(SPT_K_EXTEND);
-                        if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        if ((wst_mask & 2u) && count) hipLaunchKernelGGL((k_trace_wst<WstExtend, true>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, st, sc->d, ru, b, sc->wst_ovf.as<uint2>());
+                        else if (wst_mask & 2u) hipLaunchKernelGGL((k_trace_wst<WstExtend, false>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, st, sc->d, ru, b, sc->wst_ovf.as<uint2>());
+                        else if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (stream_e) hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (dyn_extend && count) hipLaunchKernelGGL(k_extend_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);

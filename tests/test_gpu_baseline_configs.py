@@ -159,6 +159,11 @@ SWITCHES = [
     {"SPT_NO_LDS_GEO": "1", "SPT_NO_DYN_SHADOW": "1"},
     {"SPT_NO_LDS_GEO": "1", "SPT_NO_DYN_EXTEND": "1"},
     {"SPT_NO_LDS_GEO": "1", "SPT_DYN_REFILL": "64", "SPT_DYN_STEPS": "1"},
+    {"SPT_NO_LDS_GEO": "1", "SPT_NO_STREAM": "1"},                              # the refilling state-machine walkers of trace.h for every ray class
+    {"SPT_NO_LDS_GEO": "1", "SPT_STREAM_MASK": "7"},                            # the streaming walker (stream.h) for primary, shadow and extension rays
+    {"SPT_NO_LDS_GEO": "1", "SPT_STREAM_MASK": "7", "SPT_STREAM_IFIF": "0", "SPT_STREAM_ROUNDS": "2", "SPT_STREAM_REFILL": "64"},   # while-while
+    {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3"},                               # kind-sorted traversal (wst.h) for shadow and extension rays
+    {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3", "SPT_REFERENCE_BVH": "1"},
     {"SPT_NO_PIXEL_CULL": "1"},
     {"SPT_NO_OVERLAP": "1"},
     {"SPT_PRIMARY_CHUNKS": "1"},
