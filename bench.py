@@ -43,7 +43,8 @@ def load_pkg():
 
 
 # record sizes of the queue layouts in simple-path-tracer_amd/csrc/hip/kernels.h (bytes)
-S_PATH, S_HIT, S_SHADOW, S_RAD = 72, 20, 48, 12
+S_PATH, S_HIT, S_SHADOW, S_RAD = 72, 24, 48, 12   # S_HIT: (t, v, w, prim) + (instance, source index of the path record)
+S_RAY = 32           # what a traversal reads of a path / shadow record: (origin, t_min) (direction, pdf | t_max)
 S_PATH0 = 16  # compact bounce-0 record: direction + slot
 # geometry records (SURVEY 8d / DESIGN.md section 3): node, triangle positions, triangle attributes, instance
 S_NODE, S_TRI, S_ATTR, S_INST = 64, 48, 144, 192
@@ -285,20 +286,22 @@ def main():
         fused = int(kernel_launches[2]) == 0 and int(kernel_launches[3]) == 0
         seg_s0, verts1 = st.shadow_first, st.vertices_second        # bounce 0: shadow rays issued, vertices kept for bounce 1
         later = verts - hits0                                        # path vertices of bounces >= 1
+        live = st.live_samples
         alg = {
-            # un-chunked: hit records + a zeroed slot per hit + film read / write; chunked (sample chunks per tile): every
-            # sample of a pixel inside the screen-space bound zeroes / fills its slot, the film is left to k_resolve
-            "primary": (hits0 * (S_PATH0 + S_HIT) + st.live_samples * S_RAD) if st.live_samples else
-                       hits0 * (S_PATH0 + S_HIT + S_RAD) + passes * n_pix * 2 * S_RAD,
-            # bounce-0 shade launches (one per pass): read the compact hit records, (fused) write the kept bounce-1
-            # vertices and read-modify-write a radiance slot per shadow ray, (un-fused) write shadow + path records
-            "shade_first": (hits0 * (S_PATH0 + S_HIT) + verts1 * (S_PATH + S_HIT) + seg_s0 * 2 * S_RAD) if fused else
-                           hits0 * (S_PATH0 + S_HIT) + seg_s0 * S_SHADOW + min(ext, hits0) * S_PATH,
+            # chunked (sample chunks per tile): a hit writes its compact record, a black sample writes nothing; one mask byte per 8
+            # samples of a live pixel says which samples own a radiance slot.  un-chunked: hit records + film read / write
+            "primary": (hits0 * (S_PATH0 + S_HIT) + live // 8) if live else
+                       hits0 * (S_PATH0 + S_HIT) + passes * n_pix * 2 * S_RAD,
+            # bounce-0 shade launches (one per pass): read the compact hit records, WRITE the sample's radiance slot once (the first
+            # contributions are summed in registers), (fused) write the kept bounce-1 vertices, (un-fused) shadow + path records
+            "shade_first": (hits0 * (S_PATH0 + S_HIT + S_RAD) + verts1 * (S_PATH + S_HIT)) if fused else
+                           hits0 * (S_PATH0 + S_HIT + S_RAD) + seg_s0 * S_SHADOW + min(ext, hits0) * S_PATH,
             "shade": (later * (S_PATH + S_HIT) + (later - verts1) * (S_PATH + S_HIT) + (seg_s - seg_s0) * 2 * S_RAD) if fused else
                      later * (S_PATH + S_HIT) + (seg_s - seg_s0) * S_SHADOW + max(ext - hits0, 0) * S_PATH,
             "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
-            "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
-            "resolve": (st.live_samples if st.live_samples else hits0) * S_RAD + passes * n_pix * 2 * S_RAD,
+            # the extend stage reads the ray of a path record and leaves a hit + the record's index (no copy of the record)
+            "extend": ext * S_RAY + (verts - hits0) * S_HIT,
+            "resolve": (hits0 * S_RAD + live // 8 + passes * n_pix * 2 * S_RAD) if live else hits0 * S_RAD + passes * n_pix * 2 * S_RAD,
         }
         kern = {}
         for k in (0, 6, 1, 2, 3, 4):
@@ -429,11 +432,11 @@ def other_configs(spt, device, only=""):
         vis = r.last_stats
         geo = vis.node_visits * S_NODE + vis.tri_tests * S_TRI + vis.instance_visits * S_INST
         queues = {
-            "primary": hits0 * (S_PATH0 + S_HIT) + (st.live_samples or hits0) * S_RAD,
-            "shade_first": hits0 * (S_PATH0 + S_HIT + S_ATTR) + st.shadow_first * S_SHADOW + min(ext, hits0) * S_PATH,
+            "primary": hits0 * (S_PATH0 + S_HIT) + (st.live_samples // 8 if st.live_samples else 0),
+            "shade_first": hits0 * (S_PATH0 + S_HIT + S_ATTR + S_RAD) + st.shadow_first * S_SHADOW + min(ext, hits0) * S_PATH,
             "shade": (verts - hits0) * (S_PATH + S_HIT + S_ATTR) + (seg_s - st.shadow_first) * S_SHADOW + max(ext - hits0, 0) * S_PATH,
-            "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
-            "extend": ext * S_PATH + (verts - hits0) * (S_PATH + S_HIT),
+            "shadow": seg_s * (S_RAY + 16 + 2 * S_RAD),
+            "extend": ext * S_RAY + (verts - hits0) * S_HIT,
         }
         dom = max((k for k in kms if k in queues), key=lambda k: kms[k])
         entry = {

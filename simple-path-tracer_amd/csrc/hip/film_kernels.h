@@ -11,6 +11,34 @@ __global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
     if (first >= rc.pass_samples) return;
     const size_t plane = rc.rad_plane;
     f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+    if (rc.slot_bits) {
+        // chunked k_primary: only the samples marked in slot_bits own a slot; the others were black and add nothing
+        // (film.rs:87 adds +0 for them: the same sum).  Four mask bytes = 32 samples per outer iteration, the marked
+        // slots of a byte are requested together before they are added in sample order.
+        for (uint32_t s0 = 0; s0 < rc.pass_samples; s0 += 32u) {
+            uint32_t m[4];
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g)
+                m[g] = (s0 + 8u * g < rc.pass_samples) ? rc.slot_bits[(size_t)((s0 >> 3) + g) * rc.n_pixels + lp] : 0u;
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g) {
+                if (m[g] == 0u) continue;
+                float r[8], gg[8], b[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    if ((m[g] >> k) & 1u) {
+                        const size_t ri = (size_t)(s0 + 8u * g + k) * rc.n_pixels + lp;
+                        r[k] = rc.rad[ri]; gg[k] = rc.rad[plane + ri]; b[k] = rc.rad[2 * plane + ri];
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k)
+                    if ((m[g] >> k) & 1u) sum = sum + mk3(r[k], gg[k], b[k]);
+            }
+        }
+        rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
+        return;
+    }
     // the additions are sequential (sample order = the reference's, film.rs:87), the loads are not: 8 samples
     // (24 loads) in flight per lane, which matters when a narrow shard leaves few pixels to hide latency with
     uint32_t s = first;

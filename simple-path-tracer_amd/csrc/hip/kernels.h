@@ -80,6 +80,9 @@ struct RenderCtx {
                               // (wide box filter: rad then points at the pass's first sample inside the plane)
     float* film;              // n_pixels * 3 running sums
     uint32_t* first_slot;     // per pixel: first sample of the pass that uses a rad slot
+    uint8_t* slot_bits;       // chunked k_primary only (else null): [sample / 8][pixel], bit (sample % 8) = "this sample owns a
+                              // radiance slot that was written" (a hit, or a miss that saw the environment).  A missing sample
+                              // writes nothing at all; k_resolve adds only the marked slots
     float aspect, width_inv, height_inv, spp_inv;
     float aux_dx, aux_dy;  // auxiliary-ray offsets (pt.rs:272-275), textured scenes only
     // conservative bounding sphere of all instances relative to the camera eye (primary early-out)
@@ -242,6 +245,7 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
     const bool live = in_bounds || has_env;
     const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
     const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
+    uint32_t slot_mask = 0u;     // chunked: the slot bits of the current group of 8 samples (chunk_samples is a multiple of 8)
     for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t gs = rc.pass_first + s;
         DRng rng;
@@ -282,13 +286,18 @@ __global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
                 } else {
                     rc.rad[ri] = c.x; rc.rad[plane + ri] = c.y; rc.rad[2 * plane + ri] = c.z;
                 }
-            } else if (first != rc.pass_samples) {
+            } else if (!kChunked && first != rc.pass_samples) {   // chunked: a black sample leaves no trace (slot_bits)
                 rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
             }
         }
-        if (hit) {
-            if (first == rc.pass_samples) first = s;
-            rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
+        // (a hit's slot is not zeroed here: the bounce-0 shade kernel WRITES the sample's first contributions, see k_shade)
+        if (hit && first == rc.pass_samples) first = s;
+        if (kChunked) {
+            slot_mask |= ((hit || (valid && has_env)) ? 1u : 0u) << (s & 7u);
+            if ((s & 7u) == 7u || s + 1u == s_end) {
+                if (valid) rc.slot_bits[(size_t)(s >> 3) * rc.n_pixels + lp] = (uint8_t)slot_mask;
+                slot_mask = 0u;
+            }
         }
         // (deferring this append by one iteration to overlap the counter atomic with the next sample was tried
         //  twice: at 120 VGPRs the pending state cost a wave per SIMD and it was slower, at 104 VGPRs it fits
@@ -317,6 +326,13 @@ SPT_DEV void rad_add(const RenderCtx& rc, uint32_t slot, f3 c) {
     rc.rad[slot] = rc.rad[slot] + c.x;
     rc.rad[plane + slot] = rc.rad[plane + slot] + c.y;
     rc.rad[2 * plane + slot] = rc.rad[2 * plane + slot] + c.z;
+}
+
+SPT_DEV void rad_store(const RenderCtx& rc, uint32_t slot, f3 c) {
+    const size_t plane = rc.rad_plane;
+    rc.rad[slot] = c.x;
+    rc.rad[plane + slot] = c.y;
+    rc.rad[2 * plane + slot] = c.z;
 }
 
 // ---------------------------------------------------------------------------- shade
@@ -386,6 +402,14 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
         }
         bool want_shadow = false, want_ext = false;
+        // Bounce 0 owns the first contributions of a camera sample: they are summed here, starting from the 0 the slot
+        // would hold, in the order the read-modify-writes would have been made, and the slot is WRITTEN once at the end of
+        // the iteration (k_primary does not zero it).  Later bounces and k_shadow / k_extend add to the slot as before.
+        f3 first_acc = mk3(0.0f, 0.0f, 0.0f);
+        auto slot_add = [&](uint32_t sl, f3 c) {
+            if (kFirst) first_acc = first_acc + c;
+            else rad_add(rc, sl, c);
+        };
         DRay shadow_ray, next_ray;
         float shadow_tmax = 0.0f, next_pdf = 0.0f;
         f3 contrib = mk3(0, 0, 0), thr = gray(1.0f), lsi = mk3(0, 0, 0);
@@ -546,7 +570,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         env_strength_pdf(sc, ray.d, &env, &env_pdf);
                         float weight = 1.0f;
                         if (depth != 0u) weight = power_heuristic(last_pdf, pdf_env_light(sc) * env_pdf);
-                        rad_add(rc, slot, (thr * env) * weight);
+                        slot_add(slot, (thr * env) * weight);
                     }
                     alive = false;
                 } else {  // pt.rs:112-193
@@ -560,7 +584,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     if (!kSimple && luminance(le) > 0.0f) {
                         float weight = 1.0f;
                         if (depth != 0u) weight = power_heuristic(last_pdf, pdf_shape_light(sc, (uint32_t)h.inst, sflags, lsi, it, h.prim));
-                        rad_add(rc, slot, (thr * le) * weight);
+                        slot_add(slot, (thr * le) * weight);
                     }
                     f3 wo = coord.to_local(-ray.d);
                     DBxdfSample samp;
@@ -609,7 +633,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         // thing.  Resolved right here (k_shade<3> can trace), the shadow queue never sees it.
                         f3 add = thr * 0.0f;
                         if (want_shadow && !trace_any<kGeoLds>(sc, shadow_ray, shadow_tmax)) add = contrib;
-                        rad_add(rc, slot, add);
+                        slot_add(slot, add);
                         want_shadow = false;
                     }
                     next_pdf = samp.pdf;
@@ -644,7 +668,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             // the two queue counters still count the segments (spt_render_stats); the slots are not used
             const PendingPush ps = wave_push_issue(want_shadow, shadow_count);
             const PendingPush pe = wave_push_issue(want_ext, ext_count);
-            if (want_shadow && !trace_any<true>(sc, shadow_ray, shadow_tmax)) rad_add(rc, slot, contrib);   // k_shadow
+            if (want_shadow && !trace_any<true>(sc, shadow_ray, shadow_tmax)) slot_add(slot, contrib);   // k_shadow
             bool keep = false;                                                                               // k_extend
             DHit nh;
             nh.inst = -1; nh.t = SPT_F32_MAX; nh.prim = -1; nh.v = 0.0f; nh.w = 0.0f;
@@ -657,9 +681,10 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                     float env_pdf;
                     env_strength_pdf(sc, next_ray.d, &env, &env_pdf);
                     float weight = power_heuristic(next_pdf, pdf_env_light(sc) * env_pdf);
-                    rad_add(rc, slot, (thr * env) * weight);
+                    slot_add(slot, (thr * env) * weight);
                 }
             }
+            if (kFirst && active) rad_store(rc, slot, first_acc);
             (void)wave_push_finish(ps);
             (void)wave_push_finish(pe);
             const uint32_t ns = qbase + wave_push(keep, q_count(rc.counts, bounce + 1, Q_HIT, shard));
@@ -670,6 +695,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             }
             continue;
         }
+        if (kFirst && active) rad_store(rc, slot, first_acc);   // before k_shadow / k_extend of this bounce add to it
         // both reservations in flight together: one atomic round trip per iteration instead of two
         const PendingPush ps = wave_push_issue(want_shadow, shadow_count);
         const PendingPush pe = wave_push_issue(want_ext, ext_count);
@@ -1013,6 +1039,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
     wk.cur = kNoRef;
     uint32_t s = s_begin;        // next sample to start
     uint32_t s_cur = 0u;         // sample being walked / retired
+    uint32_t slot_mask = 0u;     // chunked: the slot bits of the current group of 8 samples (chunk_samples is a multiple of 8)
     bool busy = false;
     f3 dir = mk3(0, 0, 0);
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
@@ -1062,13 +1089,18 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
                 } else {
                     rc.rad[ri] = c.x; rc.rad[plane + ri] = c.y; rc.rad[2 * plane + ri] = c.z;
                 }
-            } else if (first != rc.pass_samples) {
+            } else if (!kChunked && first != rc.pass_samples) {   // chunked: a black sample leaves no trace (slot_bits)
                 rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
             }
         }
-        if (hit) {
-            if (first == rc.pass_samples) first = s_cur;
-            rc.rad[ri] = 0.0f; rc.rad[plane + ri] = 0.0f; rc.rad[2 * plane + ri] = 0.0f;
+        // (a hit's slot is not zeroed here: the bounce-0 shade kernel WRITES the sample's first contributions, see k_shade)
+        if (hit && first == rc.pass_samples) first = s_cur;
+        if (kChunked && retire) {    // a lane retires its samples in order: s_cur runs through [s_begin, s_end)
+            slot_mask |= ((hit || has_env) ? 1u : 0u) << (s_cur & 7u);
+            if ((s_cur & 7u) == 7u || s_cur + 1u == s_end) {
+                rc.slot_bits[(size_t)(s_cur >> 3) * rc.n_pixels + lp] = (uint8_t)slot_mask;
+                slot_mask = 0u;
+            }
         }
         const uint32_t slot = shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {

@@ -498,7 +498,7 @@ struct spt_scene {
     bool swalk = false;     // the streaming walker's tables (stream.h) were built: k_*_stream serve the scene
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
-    DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, out;
+    DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, slot_bits, out;
     DeviceBuffer trace_in, trace_out, visits, wst_ovf;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
@@ -1255,6 +1255,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             sc->rad.ensure((size_t)rad64 * 3 * sizeof(float));
             sc->film.ensure((size_t)n_pix * 3 * sizeof(float));
             sc->first_slot.ensure((size_t)n_pix * sizeof(uint32_t));
+            sc->slot_bits.ensure((size_t)n_pix * ((spp_pass + 7u) / 8u));
 
             RenderCtx rc{};
             rc.cam.eye = f3{cam->eye[0], cam->eye[1], cam->eye[2]};
@@ -1383,6 +1384,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     if (const char* v = std::getenv("SPT_PRIMARY_CHUNKS")) want = (uint32_t)std::max(1, std::atoi(v));
                     want = std::max(1u, std::min(want, rc.pass_samples));
                     rc.chunk_samples = (rc.pass_samples + want - 1u) / want;
+                    rc.chunk_samples = (rc.chunk_samples + 7u) / 8u * 8u;   // slot_bits: a group of 8 samples belongs to one chunk
                     rc.primary_chunks = (rc.pass_samples + rc.chunk_samples - 1u) / rc.chunk_samples;
                 }
                 const bool stream = sc->swalk && !L;
@@ -1396,8 +1398,10 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 const uint32_t wst_mask = stream ? env_u32("SPT_WST_MASK", 0u) : 0u;
                 const uint32_t wst_grid = kShards * kWstBlocksPerShard;
                 if (wst_mask) sc->wst_ovf.ensure((size_t)wst_grid * kWstRays * kSpillStack * sizeof(uint2));   // per slot: the levels beyond kWstStack (fewer than kSpillStack)
+                rc.slot_bits = nullptr;
                 if (rc.primary_chunks > 1u || collect) {   // collect: every sample owns a slot, which is what the chunked kernel does
                     chunked_any = true;
+                    rc.slot_bits = sc->slot_bits.as<uint8_t>();
                     if (stream_p && count) hipLaunchKernelGGL((k_primary_stream<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (stream_p) hipLaunchKernelGGL((k_primary_stream<true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (L) hipLaunchKernelGGL((k_primary<true, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
