@@ -61,6 +61,10 @@ spt_status spt_host_write_exr(const char* path, const float* rgb, uint32_t width
 spt_status spt_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out);
 /* the same for a PNG or a JPEG file (told apart by content; baseline / progressive Huffman, IJG arithmetic) */
 spt_status spt_host_read_image(const char* path, uint32_t* width, uint32_t* height, uint32_t** rgba8_out);
+/* The Catmull-Clark front end on its own (CatmullClark::load, src/primitive/catmull.rs:93-101): the bicubic patches of an
+ * ASCII PLY control mesh after `fas_times` rounds of feature-adaptive subdivision, 16 control points (x, y, z) per patch;
+ * free with spt_host_free.  (A scene's `catmull_clark` primitive goes through the same code.) */
+spt_status spt_host_catmull_clark(const char* ply_path, uint32_t fas_times, uint32_t* n_patches, float** control_points_out);
 void spt_host_free(void* p);
 
 const char* spt_host_last_error(void);

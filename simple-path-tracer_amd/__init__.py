@@ -217,6 +217,7 @@ def host_lib() -> C.CDLL:
         lib.spt_host_read_exr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                           C.POINTER(C.POINTER(C.c_float))]
         lib.spt_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.spt_host_catmull_clark.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]
         lib.spt_host_free.argtypes = [C.c_void_p]
         lib.spt_host_free.restype = None
         _host_lib = lib
@@ -535,6 +536,16 @@ def read_exr(path: str) -> np.ndarray:
     ptr = C.POINTER(C.c_float)()
     _check_host(host_lib().spt_host_read_exr(os.fspath(path).encode(), C.byref(w), C.byref(h), C.byref(ptr)))
     arr = np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+    host_lib().spt_host_free(ptr)
+    return arr
+
+
+def catmull_clark_patches(ply_path: str, fas_times: int = 4) -> np.ndarray:
+    """CatmullClark::load (src/primitive/catmull.rs:93-101): (n, 4, 4, 3) Bezier control points of the subdivision surface."""
+    n = C.c_uint32()
+    ptr = C.POINTER(C.c_float)()
+    _check_host(host_lib().spt_host_catmull_clark(os.fspath(ply_path).encode(), fas_times, C.byref(n), C.byref(ptr)))
+    arr = np.ctypeslib.as_array(ptr, shape=(max(n.value, 1), 4, 4, 3))[: n.value].copy()
     host_lib().spt_host_free(ptr)
     return arr
 

@@ -1,5 +1,7 @@
 // C entry points of libspt_host.so (see include/spt_host.h for the reference
 // counterparts of each function).
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -23,6 +25,27 @@ struct spt_host_scene {
 extern "C" {
 
 const char* spt_host_last_error(void) { return g_error.c_str(); }
+
+spt_status spt_host_catmull_clark(const char* ply_path, uint32_t fas_times, uint32_t* n_patches, float** control_points_out) {
+    if (!ply_path || !n_patches || !control_points_out) { set_error("catmull_clark: null argument"); return SPT_ERR_INVALID_ARG; }
+    *n_patches = 0;
+    *control_points_out = nullptr;
+    try {
+        const std::vector<float> cps = catmull_clark_patches(ply_path, fas_times);
+        float* out = static_cast<float*>(std::malloc(std::max<size_t>(cps.size(), 1) * sizeof(float)));
+        if (!out) { set_error("catmull_clark: out of memory"); return SPT_ERR_OUT_OF_MEMORY; }
+        std::memcpy(out, cps.data(), cps.size() * sizeof(float));
+        *n_patches = (uint32_t)(cps.size() / 48);
+        *control_points_out = out;
+        return SPT_OK;
+    } catch (const HostError& e) {
+        set_error(e.msg);
+        return e.code;
+    } catch (const std::exception& e) {
+        set_error(std::string("catmull_clark: ") + e.what());
+        return SPT_HOST_ERR_PARSE;
+    }
+}
 
 spt_status spt_host_load_scene(const char* scene_json_path, spt_host_scene** out) {
     if (!scene_json_path || !out) { set_error("load_scene: null argument"); return SPT_ERR_INVALID_ARG; }

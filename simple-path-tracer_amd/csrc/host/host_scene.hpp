@@ -48,6 +48,8 @@ struct HostScene {
 };
 
 HostScene* load_scene_file(const std::string& path);
+// catmull.cpp: 16 control points (x, y, z) per bicubic patch of the Catmull-Clark surface of an ASCII PLY control mesh
+std::vector<float> catmull_clark_patches(const std::string& ply_path, uint32_t fas_times);
 void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
 void decode_png_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);   // PNG or JPEG (by content)
 void decode_jpeg_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);

@@ -390,6 +390,7 @@ bool jvec(const JsonValue* v, size_t n, float* out) {
 }
 
 struct PrimRec { uint32_t type; uint32_t id; Box box; };
+constexpr uint32_t kPrimCatmullClark = 100u;   // host-only kind: PrimRec::id indexes Loader::catmulls; its patches become Bezier instances
 struct SurfaceRec { uint32_t index; bool emissive; };
 
 }  // namespace
@@ -411,6 +412,9 @@ struct SceneBuilder {
     std::map<std::string, PrimRec> prims;
     std::vector<V3> avg_emissive;                     // per surface
     struct InstRec { spt_instance inst; Affine trans; std::string name; };
+    struct CatmullRec { std::string ply_path, label; uint32_t fas_times = 4; bool loaded = false; uint32_t first_patch = 0, n_patches = 0; };
+    std::vector<CatmullRec> catmulls;
+    std::set<std::string> catmull_instances;
     std::map<std::string, InstRec> instances;         // name-sorted (Q7: reference order is HashMap order)
     std::map<std::string, spt_light> lights;
     bool has_env = false;
@@ -834,9 +838,15 @@ struct SceneBuilder {
             rec.id = (uint32_t)hs.bezier_patches.size();
             hs.bezier_patches.push_back(bp);
         } else if (ty == "catmull_clark") {
-            if (prims.count(name) || unsupported_prims.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated primitive name '" + name + "'");
-            unsupported_prims[name] = p.name() + ": primitive type '" + ty + "' is outside the hot-path scope (SURVEY 2 #4)";
-            return;
+            // CatmullClark::load (src/primitive/catmull.rs:93-101).  The control mesh is read and subdivided when the first
+            // instance uses the primitive (catmull.cpp): the reference's scene files pull whole primitive libraries in
+            CatmullRec cr;
+            cr.ply_path = p.get_file_path("ply_file");
+            cr.fas_times = p.contains("fas_times") ? (uint32_t)std::max(0, p.get_int("fas_times")) : 4u;
+            cr.label = p.name();
+            rec.type = kPrimCatmullClark;
+            rec.id = (uint32_t)catmulls.size();
+            catmulls.push_back(cr);
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
         }
@@ -969,8 +979,45 @@ struct SceneBuilder {
         if (unsupported_prims.count(pn)) throw HostError(SPT_HOST_ERR_UNSUPPORTED, unsupported_prims[pn]);
         auto pi = prims.find(pn);
         if (pi == prims.end()) throw HostError(SPT_HOST_ERR_SCHEMA, "There is no primitive named '" + pn + "'");
-        if (instances.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated instance name '" + name + "'");
-        instances[name] = make_instance(name, trans, pi->second, surf);
+        if (instances.count(name) || catmull_instances.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated instance name '" + name + "'");
+        if (pi->second.type == kPrimCatmullClark) {
+            // CatmullClark = BvhAccel<CubicBezier> (catmull.rs:82-85, 445): every patch becomes an instance of its own with this
+            // instance's transform and surface, and the scene's TLAS is that BVH.  (Instance order is name order: the
+            // patches of one primitive stay together, zero-padded.)
+            CatmullRec& cr = catmulls[pi->second.id];
+            if (!cr.loaded) {
+                const std::vector<float> cps = catmull_clark_patches(cr.ply_path, cr.fas_times);
+                cr.first_patch = (uint32_t)hs.bezier_patches.size();
+                cr.n_patches = (uint32_t)(cps.size() / 48);
+                if (cr.n_patches == 0) throw HostError(SPT_HOST_ERR_SCHEMA, cr.label + ": the control mesh yields no patch");
+                for (uint32_t k = 0; k < cr.n_patches; ++k) {
+                    spt_bezier_patch bp;
+                    std::memset(&bp, 0, sizeof bp);
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j)
+                            for (int c = 0; c < 3; ++c) bp.cp[i][j][c] = cps[(size_t)k * 48 + (size_t)(i * 4 + j) * 3 + (size_t)c];
+                    hs.bezier_patches.push_back(bp);
+                }
+                cr.loaded = true;
+            }
+            if (luminance(V3{hs.surfaces[surf].emissive[0], hs.surfaces[surf].emissive[1], hs.surfaces[surf].emissive[2]}) > 0.0f)
+                throw HostError(SPT_HOST_ERR_UNSUPPORTED, p.name() + ": an emissive surface on a catmull_clark primitive (CatmullClark::sample / surface_area are unimplemented in the reference, catmull.rs:120-130)");
+            char suffix[32];
+            for (uint32_t k = 0; k < cr.n_patches; ++k) {
+                const spt_bezier_patch& bp = hs.bezier_patches[cr.first_patch + k];
+                PrimRec pr;
+                pr.type = SPT_PRIM_BEZIER;
+                pr.id = cr.first_patch + k;
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) pr.box.grow(V3{bp.cp[i][j][0], bp.cp[i][j][1], bp.cp[i][j][2]});
+                std::snprintf(suffix, sizeof suffix, "\x01patch%07u", k);
+                const std::string pname = name + suffix;
+                instances[pname] = make_instance(pname, trans, pr, surf);
+            }
+            catmull_instances.insert(name);
+        } else {
+            instances[name] = make_instance(name, trans, pi->second, surf);
+        }
         p.check_unused();
     }
 

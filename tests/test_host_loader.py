@@ -80,13 +80,18 @@ def test_out_of_scope_features_are_reported_when_used(tmp_path):
     lib_only["primitives"].append({"type": "catmull_clark", "name": "cc", "ply_file": "x.ply"})
     assert load(tmp_path, lib_only).desc.n_instances == 1
     for mutate in (lambda s: s["instances"].append({"name": "j", "primitive": "s", "material": "p"}),
-                   lambda s: s["instances"].append({"name": "j", "primitive": "cc", "material": "m"}),
                    lambda s: s["surfaces"].append({"name": "sf", "material": "p"})):
         bad = json.loads(json.dumps(lib_only))
         mutate(bad)
         with pytest.raises(spt.SptError) as e:
             load(tmp_path, bad)
         assert e.value.status == 103 and "outside the hot-path scope" in str(e.value)
+    # (a catmull_clark primitive is read when its first instance is made: tests/test_catmull.py)
+    used = json.loads(json.dumps(lib_only))
+    used["instances"].append({"name": "j", "primitive": "cc", "material": "m"})
+    with pytest.raises(spt.SptError) as e:
+        load(tmp_path, used)
+    assert e.value.status == 100 and "x.ply" in str(e.value)
     dup = json.loads(json.dumps(lib_only))
     dup["materials"].append({"type": "lambert", "name": "p", "albedo": "w"})
     with pytest.raises(spt.SptError) as e:
