@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 9
+#define SPT_ABI_VERSION 10
 
 typedef int32_t spt_status;
 enum {
@@ -126,7 +126,10 @@ enum {
     SPT_BXDF_SPECULAR_DIELECTRIC = 4,  /* src/bxdf/specular_dielectric.rs   */
     SPT_BXDF_PSEUDO = 5,               /* src/bxdf/pseudo.rs                */
     SPT_BXDF_MICROFACET_PLASTIC = 6,   /* src/bxdf/microfacet_plastic.rs    */
-    SPT_BXDF_SPECULAR_PLASTIC = 7      /* src/bxdf/specular_plastic.rs      */
+    SPT_BXDF_SPECULAR_PLASTIC = 7,     /* src/bxdf/specular_plastic.rs      */
+    SPT_BXDF_PNDF_CONDUCTOR = 8,       /* MicrofacetConductor over a PndfMicrofacet (src/bxdf/microfacet.rs:56-170); only ever
+                                          the result of a per-hit recipe (SPT_MAT_PNDF_CONDUCTOR), never a constant material */
+    SPT_BXDF_PNDF_PLASTIC = 9          /* MicrofacetPlastic over a PndfMicrofacet (SPT_MAT_PNDF_PLASTIC), per hit only too */
 };
 /* plastic lobes = Fresnel-weighted specular coat over a substrate (materials plastic, pbr_metallic,
  * pbr_specular; src/material/{plastic,pbr_metallic,pbr_specular}.rs) */
@@ -140,7 +143,7 @@ typedef struct spt_material {
     float ax, ay;    /* GGX roughness_x / roughness_y (as the material hands them to GgxMicrofacet) */
     float ior;       /* dielectric / plastic: int_ior / ext_ior                                     */
     float c2[3];     /* Diffuse substrate: bxdf_wo_fresnel (Diffuse::new, substrate.rs:127-137)     */
-    uint32_t fresnel;    /* SPT_FRESNEL_*   (plastic lobes) */
+    uint32_t fresnel;    /* SPT_FRESNEL_*   (plastic lobes; conductors: SCHLICK = SchlickFresnel with r0 = c0, else ConductorFresnel) */
     uint32_t substrate;  /* SPT_SUBSTRATE_* (plastic lobes) */
     uint32_t recipe;     /* 0: the constants above are the Bxdf; k > 0: material_recipes[k - 1] is
                             evaluated at every hit (some parameter is an image texture) and the
@@ -181,7 +184,10 @@ typedef struct spt_image_level { uint32_t width, height, first_texel, pad; } spt
 /* A material whose parameters are not all constant: MaterialT::bxdf_context
  * (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs) restated as data. */
 enum { SPT_MAT_LAMBERT = 0, SPT_MAT_CONDUCTOR = 1, SPT_MAT_DIELECTRIC = 2, SPT_MAT_PLASTIC = 3,
-       SPT_MAT_PBR_METALLIC = 4, SPT_MAT_PBR_SPECULAR = 5, SPT_MAT_SUBSURFACE = 6 };
+       SPT_MAT_PBR_METALLIC = 4, SPT_MAT_PBR_SPECULAR = 5, SPT_MAT_SUBSURFACE = 6,
+       SPT_MAT_PNDF_CONDUCTOR = 7,     /* pndf_conductor.rs:156-196: tex[0] albedo, tex[1] = index into pndfs (not a texture),
+                                          tex[2] fallback_roughness (read when the pixel footprint sigma_p is 0) */
+       SPT_MAT_PNDF_PLASTIC = 8 };     /* pndf_plastic.rs:163-211: the same slots + ior; DielectricFresnel, Diffuse substrate */
 typedef struct spt_material_recipe {
     uint32_t type;         /* SPT_MAT_* */
     uint32_t tex[4];       /* texture indices: [0] albedo | ior | base_color | diffuse, [1] ior_k | metallic | specular | ld,
@@ -190,6 +196,32 @@ typedef struct spt_material_recipe {
     uint32_t metal_chan;   /* SPT_CHAN_* read from tex[1] of PBR_METALLIC                      */
     float ior;             /* DIELECTRIC / PLASTIC: int_ior / ext_ior                          */
 } spt_material_recipe;     /* 8 words */
+
+/* ---- position-normal distributions ("glints", src/bxdf/pndf_bvh.rs, src/material/pndf_conductor.rs) -----------------
+ * One Gaussian term per cell of the material's normal map (PndfGaussTerm, pndf_bvh.rs:4-11, 405-437). */
+typedef struct spt_pndf_term {
+    float u[2];        /* cell centre in texture space                                 */
+    float s[2];        /* (x, y) of the normal there                                     */
+    float jacobian[4]; /* ds/du, columns (dsdu, dsdv) (glam Mat2: x_axis, y_axis)      */
+    float mat_a[4], mat_s[4], mat_mu[4];   /* PndfGaussTerm::new, column-major like glam */
+} spt_pndf_term;       /* 20 words = 80 B */
+/* A node of PndfBvh (4-D boxes over (u, s), pndf_bvh.rs:19-25, 124-190) or of PndfUvBvh (2-D boxes over u, the last two
+ * box coordinates are 0; pndf_bvh.rs:35-41, 266-333).  Both split their index range in the middle, without sorting. */
+typedef struct spt_pndf_node {
+    float bmin[4], bmax[4];
+    uint32_t start, end;   /* range in pndf_refs, relative to the owning tree's first ref */
+    uint32_t lc, rc;       /* children (absolute node indices), 0xffffffff in a leaf       */
+} spt_pndf_node;       /* 12 words = 48 B */
+typedef struct spt_pndf {  /* PndfConductor + PndfAccel (pndf_conductor.rs:16-28, pndf_bvh.rs:49-92) */
+    uint32_t first_term, n_terms;       /* pndf_terms */
+    uint32_t s_block_count;             /* the s-plane [-1, 1]^2 is cut into s_block_count^2 blocks, one PndfBvh each */
+    uint32_t first_root;                /* pndf_roots[first_root + x * s_block_count + y] = root node of that block or 0xffffffff,
+                                           followed by the first ref of the block's term list */
+    uint32_t uv_root, uv_first_ref;     /* PndfUvBvh over all terms */
+    float sigma_r, sigma_hx, sigma_hy;
+    float tiling[2], offset[2];         /* base_normal.tiling() / offset() (texcoords -> u) */
+    uint32_t pad[3];
+} spt_pndf;            /* 16 words = 64 B */
 
 enum { SPT_SURF_DOUBLE_SIDED = 1u };
 typedef struct spt_surface {  /* src/core/surface.rs:14-22 */
@@ -272,6 +304,12 @@ typedef struct spt_scene_desc {
     uint32_t n_material_recipes;  const spt_material_recipe* material_recipes;
     /* bicubic Bezier patches (instances with prim_type SPT_PRIM_BEZIER) */
     uint32_t n_bezier_patches;    const spt_bezier_patch* bezier_patches;
+    /* position-normal distributions (materials with a SPT_MAT_PNDF_CONDUCTOR / _PLASTIC recipe; ABI v10) */
+    uint32_t n_pndfs;             const spt_pndf* pndfs;
+    uint32_t n_pndf_terms;        const spt_pndf_term* pndf_terms;
+    uint32_t n_pndf_nodes;        const spt_pndf_node* pndf_nodes;
+    uint32_t n_pndf_refs;         const uint32_t* pndf_refs;     /* term indices (absolute), the trees' term lists back to back */
+    uint32_t n_pndf_roots;        const uint32_t* pndf_roots;    /* pairs (root node, first ref) per s-block                    */
 } spt_scene_desc;
 
 /* PerspectiveCamera after ::new (src/camera/perspective.rs:15-27). */

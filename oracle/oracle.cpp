@@ -51,6 +51,7 @@
 
 #include "../include/spt_abi.h"
 #include "../include/spt_detmath.h"
+#include "../include/spt_pndf.h"
 #include "oracle.h"
 
 namespace {
@@ -117,6 +118,15 @@ struct Rng {
     spt_rng s;
     float uniform_1d() { return spt_rng_f32(&s); }
     void uniform_2d(float* a, float* b) { *a = uniform_1d(); *b = uniform_1d(); }
+    // Rng::gaussian_2d (src/core/rng.rs:28-42): Box-Muller, redrawing while the first number is <= 1e-6
+    void gaussian_2d(float mu, float sigma, float* x, float* y) {
+        float rx, ry;
+        do { uniform_2d(&rx, &ry); } while (!(rx > 1e-6f));
+        const float mag = sigma * spt_sqrt(-2.0f * spt_log(rx));
+        const float temp = 2.0f * SPT_PI * ry;
+        *x = mag * spt_cos(temp) + mu;
+        *y = mag * spt_sin(temp) + mu;
+    }
 };
 
 // src/core/ray.rs:2-27 (aux rays are only consumed by image textures: not carried)
@@ -939,6 +949,42 @@ inline spt_material material_at(const Ctx& cx, const spt_material& constant, con
         }
         break;
     }
+    case SPT_MAT_PNDF_CONDUCTOR:    // pndf_conductor.rs:156-196
+    case SPT_MAT_PNDF_PLASTIC: {    // pndf_plastic.rs:163-211
+        const bool plastic = r.type == SPT_MAT_PNDF_PLASTIC;
+        const spt_pndf& pd = cx.d->pndfs[r.tex[1]];
+        const Color albedo = tex_color(cx, r.tex[0], in);
+        store(m.c0, albedo);
+        if (plastic) {   // DielectricFresnel::new(ior), Diffuse::new(albedo, ior) (substrate.rs:127-137)
+            m.ior = r.ior;
+            m.fresnel = SPT_FRESNEL_DIELECTRIC;
+            m.substrate = SPT_SUBSTRATE_DIFFUSE;
+            float fdr = 2.0f * fresnel_moment1(1.0f / r.ior);
+            store(m.c2, (albedo * SPT_FRAC_1_PI) / (((gray(1.0f) - albedo * fdr) * r.ior) * r.ior));
+        } else {
+            m.fresnel = SPT_FRESNEL_SCHLICK;
+        }
+        const float ux = spt_pndf_wrap(inter.texcoords[0] * pd.tiling[0] + pd.offset[0]), uy = spt_pndf_wrap(inter.texcoords[1] * pd.tiling[1] + pd.offset[1]);
+        const float dxx = inter.duvdx[0] * pd.tiling[0], dxy = inter.duvdx[1] * pd.tiling[1];
+        const float dyx = inter.duvdy[0] * pd.tiling[0], dyy = inter.duvdy[1] * pd.tiling[1];
+        const float sigma_p = spt_max(spt_sqrt(dxx * dxx + dxy * dxy), spt_sqrt(dyx * dyx + dyy * dyy)) / 3.0f;
+        if (sigma_p > 0.0f) {
+            // PndfMicrofacet::new (microfacet.rs:67-95): the normalisation of the footprint's terms
+            spt_pndf_view v{&pd, cx.d->pndf_terms, cx.d->pndf_nodes, cx.d->pndf_refs, cx.d->pndf_roots};
+            const float sum = spt_pndf_uv_walk(&v, ux, uy, sigma_p, 0, 0.0f, 0.0f, nullptr);
+            m.bxdf = plastic ? SPT_BXDF_PNDF_PLASTIC : SPT_BXDF_PNDF_CONDUCTOR;
+            m.ax = ux; m.ay = uy;
+            m.c1[0] = 1.0f / sum;            // per-hit record of the two P-NDF lobes: (ax, ay) = u, c1 = (1 / sum, sigma_p, table)
+            m.c1[1] = sigma_p;
+            m.c1[2] = spt_u2f(r.tex[1]);
+        } else {
+            const float fr = tex_float(cx, r.tex[2], in, r.rough_chan);
+            m.ax = m.ay = fr * fr;
+            if (plastic) m.bxdf = m.ax < 0.0001f ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+            else m.bxdf = m.ax < 0.0001f ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
+        }
+        break;
+    }
     default: {  // pbr_specular.rs:60-92
         store(m.c0, tex_color(cx, r.tex[0], in));
         store(m.c1, tex_color(cx, r.tex[1], in));
@@ -1096,13 +1142,18 @@ struct BxdfSample {
     float pdf;
 };
 
-inline Color mat_fresnel(const spt_material& mt, Vec3 i, Vec3 n) {  // src/bxdf/fresnel.rs:29-59
-    if (mt.bxdf == SPT_BXDF_MICROFACET_CONDUCTOR || mt.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR)
-        return fresnel_conductor_n(col(mt.c0), col(mt.c1), i, n);
-    return gray(fresnel_n(mt.ior, i, n));
-}
 // SchlickFresnel::fresnel (fresnel.rs:49-52) = schlick_fresnel_with_r0 (util.rs:119-121), cos = i.n unclamped
 inline float pow5(float x) { return x * x * x * x * x; }
+inline Color mat_fresnel(const spt_material& mt, Vec3 i, Vec3 n) {  // src/bxdf/fresnel.rs:29-59
+    if (mt.bxdf == SPT_BXDF_MICROFACET_CONDUCTOR || mt.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR || mt.bxdf == SPT_BXDF_PNDF_CONDUCTOR) {
+        if (mt.fresnel == SPT_FRESNEL_SCHLICK) {   // the conductors of pndf_conductor.rs: SchlickFresnel::new(albedo)
+            const Color r0 = col(mt.c0);
+            return r0 + (gray(1.0f) - r0) * pow5(1.0f - dot(i, n));
+        }
+        return fresnel_conductor_n(col(mt.c0), col(mt.c1), i, n);
+    }
+    return gray(fresnel_n(mt.ior, i, n));
+}
 inline Color plastic_fresnel(const spt_material& mt, Vec3 i, Vec3 n) {
     if (mt.fresnel == SPT_FRESNEL_SCHLICK) {
         Color r0 = col(mt.c1);
@@ -1216,9 +1267,59 @@ bool subsurface_probe(const spt_material& mt, Rng& rng, SubsurfaceIo& io) {
     return true;
 }
 
-BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng, SubsurfaceIo* ss = nullptr) {
+// PndfMicrofacet (src/bxdf/microfacet.rs:56-170) over the per-hit constants material_at left in the material record
+inline spt_pndf_view pndf_view(const spt_scene_desc* d, const spt_material& mt) {
+    return spt_pndf_view{d->pndfs + spt_f2u(mt.c1[2]), d->pndf_terms, d->pndf_nodes, d->pndf_refs, d->pndf_roots};
+}
+inline float pndf_half_pdf(const spt_scene_desc* d, const spt_material& mt, Vec3 half) {   // microfacet.rs:142-154
+    const spt_pndf_view v = pndf_view(d, mt);
+    return spt_pndf_calc(&v, mt.c1[1], spt_pndf_term_coe(v.pd, mt.c1[0]), mt.ax, mt.ay, half.x, half.y);
+}
+inline float pndf_ndf_visible(const spt_scene_desc* d, const spt_material& mt, Vec3 wo, Vec3 wi, Vec3 half) {   // microfacet.rs:156-169
+    const float pndf = pndf_half_pdf(d, mt, half);
+    const float visible = 0.25f / spt_max(wi.z * wo.z, 0.0001f);
+    return pndf / spt_max(half.z, 0.0001f) * visible;
+}
+inline Vec3 pndf_sample_half(const spt_scene_desc* d, const spt_material& mt, Rng& rng, float* pdf) {   // microfacet.rs:98-140
+    const spt_pndf_view v = pndf_view(d, mt);
+    const spt_pndf& pd = *v.pd;
+    const float sigma_p = mt.c1[1];
+    const float sigma_p_sqr = sigma_p * sigma_p, sigma_p_sqr_inv = 1.0f / sigma_p_sqr;
+    const float sigma_h_sqr = pd.sigma_hx * pd.sigma_hy, sigma_h_sqr_inv = 1.0f / sigma_h_sqr;
+    const float sigma_sqr_sum_inv = 1.0f / (sigma_p_sqr + sigma_h_sqr);
+    const float rand = rng.uniform_1d();
+    uint32_t ti = 0xffffffffu;
+    spt_pndf_uv_walk(&v, mt.ax, mt.ay, sigma_p, 1, mt.c1[0], rand, &ti);
+    if (ti == 0xffffffffu) ti = pd.first_term;   // no term within reach (the reference indexes an empty list there)
+    const spt_pndf_term& g = v.terms[ti];
+    const float mux = sigma_sqr_sum_inv * (sigma_h_sqr * mt.ax + sigma_p_sqr * g.u[0]), muy = sigma_sqr_sum_inv * (sigma_h_sqr * mt.ay + sigma_p_sqr * g.u[1]);
+    const float sigma = 1.0f / spt_sqrt(sigma_p_sqr_inv + sigma_h_sqr_inv);
+    float gx, gy;
+    rng.gaussian_2d(0.0f, sigma, &gx, &gy);
+    const float ux = mux + gx, uy = muy + gy;
+    float jx, jy;
+    spt_m2_mul(g.jacobian, ux - g.u[0], uy - g.u[1], &jx, &jy);
+    const float smx = g.s[0] + jx, smy = g.s[1] + jy;
+    rng.gaussian_2d(0.0f, pd.sigma_r, &gx, &gy);
+    const float sx = smx + gx, sy = smy + gy;
+    const Vec3 half = normalize(v3(sx, sy, spt_sqrt(spt_clamp(1.0f - (sx * sx + sy * sy), 0.0f, 1.0f))));
+    *pdf = spt_pndf_calc(&v, sigma_p, spt_pndf_term_coe(v.pd, mt.c1[0]), mt.ax, mt.ay, sx, sy);
+    return half;
+}
+
+BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng, SubsurfaceIo* ss = nullptr, const spt_scene_desc* d = nullptr) {
     BxdfSample s;
     switch (mt.bxdf) {
+    case SPT_BXDF_PNDF_CONDUCTOR: {  // MicrofacetConductor::sample (microfacet_conductor.rs:23-42) over a PndfMicrofacet
+        float half_pdf;
+        Vec3 half = pndf_sample_half(d, mt, rng, &half_pdf);
+        Color fr = mat_fresnel(mt, wo, half);
+        Vec3 wi = reflect_n(wo, half);
+        s.wi = wi; s.dir = REFLECT;
+        s.bxdf = fr * pndf_ndf_visible(d, mt, wo, wi, half);
+        s.pdf = half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        return s;
+    }
     case SPT_BXDF_LAMBERT: {  // src/bxdf/lambert.rs:20-36 + rng.rs:72-80
         float rx, ry;
         rng.uniform_2d(&rx, &ry);
@@ -1298,9 +1399,11 @@ BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng,
         }
         return s;
     }
+    case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC:
     case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:26-79, specular_plastic.rs:19-63
-        const bool rough = mt.bxdf == SPT_BXDF_MICROFACET_PLASTIC;
+        const bool glint = mt.bxdf == SPT_BXDF_PNDF_PLASTIC;   // the same lobe over a PndfMicrofacet
+        const bool rough = mt.bxdf == SPT_BXDF_MICROFACET_PLASTIC || glint;
         Color fresnel_macro = plastic_fresnel(mt, wo, v3(0, 0, 1));
         float specular_weight = luminance(fresnel_macro);
         float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * substrate_reflectance(mt));
@@ -1312,11 +1415,16 @@ BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng,
             float specular_pdf;
             if (rough) {
                 float r0, r1, half_pdf;
-                rng.uniform_2d(&r0, &r1);
-                Vec3 half = ggx_smith_vndf_sample(m, wo, mt.ax, mt.ay, r0, r1, &half_pdf);
+                Vec3 half;
+                if (glint) {
+                    half = pndf_sample_half(d, mt, rng, &half_pdf);
+                } else {
+                    rng.uniform_2d(&r0, &r1);
+                    half = ggx_smith_vndf_sample(m, wo, mt.ax, mt.ay, r0, r1, &half_pdf);
+                }
                 Color fr = plastic_fresnel(mt, wo, half);
                 wi = reflect_n(wo, half);
-                specular_bxdf = fr * ndf_visible(mt, wo, wi, half);
+                specular_bxdf = fr * (glint ? pndf_ndf_visible(d, mt, wo, wi, half) : ndf_visible(mt, wo, wi, half));
                 specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
             } else {
                 wi = reflect(wo);
@@ -1360,10 +1468,10 @@ BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng,
             float specular_pdf;
             if (rough) {
                 Vec3 half = half_from_reflect(wo, wi);
-                float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+                float half_pdf = glint ? pndf_half_pdf(d, mt, half) : ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
                 specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
                 Color fr = plastic_fresnel(mt, wo, half);
-                specular_bxdf = fr * ndf_visible(mt, wo, wi, half);
+                specular_bxdf = fr * (glint ? pndf_ndf_visible(d, mt, wo, wi, half) : ndf_visible(mt, wo, wi, half));
             } else {
                 specular_pdf = reflect_pdf;
                 specular_bxdf = fresnel_macro / spt_abs(wi.z);
@@ -1383,8 +1491,14 @@ BxdfSample bxdf_sample(const Math& m, const spt_material& mt, Vec3 wo, Rng& rng,
     }
 }
 
-float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi) {
+float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi, const spt_scene_desc* d = nullptr) {
     switch (mt.bxdf) {
+    case SPT_BXDF_PNDF_CONDUCTOR:  // microfacet_conductor.rs:44-53
+        if (wo.z * wi.z >= 0.0f) {
+            Vec3 half = half_from_reflect(wo, wi);
+            return pndf_half_pdf(d, mt, half) / (4.0f * spt_abs(dot(wo, half)));
+        }
+        return 1.0f;
     case SPT_BXDF_LAMBERT:  // lambert.rs:38-44 (1.0, not 0, across hemispheres: quirk Q15)
         return (wo.z * wi.z >= 0.0f) ? spt_abs(wi.z) * SPT_FRAC_1_PI : 1.0f;
     case SPT_BXDF_MICROFACET_CONDUCTOR:  // microfacet_conductor.rs:44-53
@@ -1414,6 +1528,7 @@ float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi) {
         float reflect_pdf = luminance(mat_fresnel(mt, wo, v3(0, 0, 1)));
         return (wo.z * wi.z >= 0.0f) ? reflect_pdf : 1.0f - reflect_pdf;
     }
+    case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC:
     case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:81-99, specular_plastic.rs:65-80
         if (!(wo.z * wi.z >= 0.0f)) return 1.0f;
@@ -1422,9 +1537,9 @@ float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi) {
         float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * substrate_reflectance(mt));
         float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
         float specular_pdf;
-        if (mt.bxdf == SPT_BXDF_MICROFACET_PLASTIC) {
+        if (mt.bxdf != SPT_BXDF_SPECULAR_PLASTIC) {
             Vec3 half = half_from_reflect(wo, wi);
-            float half_pdf = ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
+            float half_pdf = mt.bxdf == SPT_BXDF_PNDF_PLASTIC ? pndf_half_pdf(d, mt, half) : ggx_smith_vndf_pdf(half, wo, mt.ax, mt.ay);
             specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
         } else {
             specular_pdf = reflect_pdf;
@@ -1437,8 +1552,14 @@ float bxdf_pdf(const spt_material& mt, Vec3 wo, Vec3 wi) {
     }
 }
 
-Color bxdf_eval(const spt_material& mt, Vec3 wo, Vec3 wi) {
+Color bxdf_eval(const spt_material& mt, Vec3 wo, Vec3 wi, const spt_scene_desc* d = nullptr) {
     switch (mt.bxdf) {
+    case SPT_BXDF_PNDF_CONDUCTOR:  // microfacet_conductor.rs:55-64
+        if (wo.z * wi.z >= 0.0f) {
+            Vec3 half = half_from_reflect(wo, wi);
+            return mat_fresnel(mt, wo, half) * pndf_ndf_visible(d, mt, wo, wi, half);
+        }
+        return gray(0.0f);
     case SPT_BXDF_LAMBERT:  // lambert.rs:46-52
         return (wo.z * wi.z >= 0.0f) ? col(mt.c0) * SPT_FRAC_1_PI : gray(0.0f);
     case SPT_BXDF_MICROFACET_CONDUCTOR:  // microfacet_conductor.rs:55-64
@@ -1479,10 +1600,11 @@ Color bxdf_eval(const spt_material& mt, Vec3 wo, Vec3 wi) {
         }
         return gray(0.0f);
     }
+    case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC: {  // microfacet_plastic.rs:101-118
         if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
         Vec3 half = half_from_reflect(wo, wi);
-        Color refl = plastic_fresnel(mt, wo, half) * ndf_visible(mt, wo, wi, half);
+        Color refl = plastic_fresnel(mt, wo, half) * (mt.bxdf == SPT_BXDF_PNDF_PLASTIC ? pndf_ndf_visible(d, mt, wo, wi, half) : ndf_visible(mt, wo, wi, half));
         Color fresnel_macro = plastic_fresnel(mt, wo, v3(0, 0, 1));
         Color sub = (gray(1.0f) - fresnel_macro) * substrate_eval(mt, wo, wi);
         return refl + sub;
@@ -1902,7 +2024,7 @@ Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
             Vec3 wo = coord_po.to_local(-ray.direction);
             SubsurfaceIo ss;
             ss.cx = &cx; ss.po = po; ss.coord_po = coord_po;
-            BxdfSample samp = bxdf_sample(cx.m, mt, wo, rng, &ss);
+            BxdfSample samp = bxdf_sample(cx.m, mt, wo, rng, &ss, cx.d);
             if (ss.has) {  // pt.rs:147-151
                 po = ss.pi;
                 coord_po = ss.coord_pi;
@@ -1915,8 +2037,8 @@ Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
                 LightSample ls;
                 if (sample_light(cx, lsi_position, rng, &ls)) {
                     Vec3 wi = coord_po.to_local(ls.dir);
-                    Color f = bxdf_eval(mt, wo, wi);
-                    float mat_pdf = bxdf_pdf(mt, wo, wi);
+                    Color f = bxdf_eval(mt, wo, wi, cx.d);
+                    float mat_pdf = bxdf_pdf(mt, wo, wi, cx.d);
                     Ray shadow_ray = make_ray(po, ls.dir);
                     shadow_ray.t_min = T_MIN_EPS / spt_max(spt_abs(wi.z), 0.00001f);
                     if (ls.pdf != 0.0f && spt_is_finite(ls.pdf) && !aggregate_intersect_test(cx, shadow_ray, ls.dist - 0.001f)) {
@@ -2166,6 +2288,36 @@ void oracle_bxdf_eval(const spt_material* mt, const float wo[3], const float wi[
     Color f = bxdf_eval(*mt, v3(wo), v3(wi));
     bxdf_out[0] = f.r; bxdf_out[1] = f.g; bxdf_out[2] = f.b;
     *pdf_out = bxdf_pdf(*mt, v3(wo), v3(wi));
+}
+void oracle_pndf_sum(const spt_scene_desc* d, uint32_t pndf, float sigma_p, uint32_t n, const float* u, float* sum_out) {
+    spt_pndf_view v{d->pndfs + pndf, d->pndf_terms, d->pndf_nodes, d->pndf_refs, d->pndf_roots};
+    for (uint32_t i = 0; i < n; ++i) sum_out[i] = spt_pndf_uv_walk(&v, u[2 * i], u[2 * i + 1], sigma_p, 0, 0.0f, 0.0f, nullptr);
+}
+void oracle_pndf_calc(const spt_scene_desc* d, uint32_t pndf, float sigma_p, uint32_t n, const float* u, const float* s, float* out) {
+    spt_pndf_view v{d->pndfs + pndf, d->pndf_terms, d->pndf_nodes, d->pndf_refs, d->pndf_roots};
+    for (uint32_t i = 0; i < n; ++i) {
+        const float sum = spt_pndf_uv_walk(&v, u[2 * i], u[2 * i + 1], sigma_p, 0, 0.0f, 0.0f, nullptr);
+        const float term_coe = (1.0f / sum) / (2.0f * SPT_PI * v.pd->sigma_r * v.pd->sigma_r);
+        out[i] = spt_pndf_calc(&v, sigma_p, term_coe, u[2 * i], u[2 * i + 1], s[2 * i], s[2 * i + 1]);
+    }
+}
+void oracle_pndf_sample_half(const spt_scene_desc* d, uint32_t pndf, float sigma_p, const float u[2], uint64_t seed, uint32_t n, float* half_pdf_out) {
+    spt_pndf_view v{d->pndfs + pndf, d->pndf_terms, d->pndf_nodes, d->pndf_refs, d->pndf_roots};
+    spt_material mt;
+    std::memset(&mt, 0, sizeof mt);
+    const float sum = spt_pndf_uv_walk(&v, u[0], u[1], sigma_p, 0, 0.0f, 0.0f, nullptr);
+    mt.bxdf = SPT_BXDF_PNDF_CONDUCTOR;
+    mt.ax = u[0]; mt.ay = u[1];
+    mt.c1[0] = 1.0f / sum;
+    mt.c1[1] = sigma_p;
+    mt.c1[2] = spt_u2f(pndf);
+    for (uint32_t i = 0; i < n; ++i) {
+        Rng rng;
+        rng.s = spt_rng_seed(seed, i, 0u);
+        float pdf;
+        const Vec3 h = pndf_sample_half(d, mt, rng, &pdf);
+        half_pdf_out[4 * i] = h.x; half_pdf_out[4 * i + 1] = h.y; half_pdf_out[4 * i + 2] = h.z; half_pdf_out[4 * i + 3] = pdf;
+    }
 }
 float oracle_fresnel_dielectric(float ior, const float i[3], const float n[3]) { return fresnel_n(ior, v3(i), v3(n)); }
 float oracle_henyey_greenstein(float g, float c) { return henyey_greenstein(g, c); }

@@ -56,6 +56,11 @@ void oracle_calc_differential(const float* ray18, const float* hit10, float duvd
 void oracle_ss_sp(const float d[3], float r, float out[3]);
 float oracle_ss_sample_r(float rand);
 void oracle_ss_cdf(uint32_t i, float xy[2]);
+/* P-NDF seams (src/bxdf/pndf_bvh.rs): PndfUvBvh::find_terms' sum and PndfAccel::calc for n points (u = 2 floats, s = 2 floats each),
+ * and PndfMicrofacet::sample_half for n random streams (out: half.xyz, pdf) */
+void oracle_pndf_sum(const spt_scene_desc* d, uint32_t pndf, float sigma_p, uint32_t n, const float* u, float* sum_out);
+void oracle_pndf_calc(const spt_scene_desc* d, uint32_t pndf, float sigma_p, uint32_t n, const float* u, const float* s, float* out);
+void oracle_pndf_sample_half(const spt_scene_desc* d, uint32_t pndf, float sigma_p, const float u[2], uint64_t seed, uint32_t n, float* half_pdf_out);
 void oracle_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 uint64_t oracle_rng_state(uint64_t seed, uint32_t pixel, uint32_t sample);
 void oracle_r2_offsets(uint32_t pixel, uint32_t spp, uint32_t n, float* out);

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 9
+SPT_ABI_VERSION = 10
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -125,6 +125,22 @@ class Env(C.Structure):
                 ("scale", C.c_float * 3), ("alias", AliasTable)]
 
 
+class PndfTerm(C.Structure):
+    _fields_ = [("u", C.c_float * 2), ("s", C.c_float * 2), ("jacobian", C.c_float * 4), ("mat_a", C.c_float * 4),
+                ("mat_s", C.c_float * 4), ("mat_mu", C.c_float * 4)]
+
+
+class PndfNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 4), ("bmax", C.c_float * 4), ("start", C.c_uint32), ("end", C.c_uint32),
+                ("lc", C.c_uint32), ("rc", C.c_uint32)]
+
+
+class Pndf(C.Structure):
+    _fields_ = [("first_term", C.c_uint32), ("n_terms", C.c_uint32), ("s_block_count", C.c_uint32), ("first_root", C.c_uint32),
+                ("uv_root", C.c_uint32), ("uv_first_ref", C.c_uint32), ("sigma_r", C.c_float), ("sigma_hx", C.c_float),
+                ("sigma_hy", C.c_float), ("tiling", C.c_float * 2), ("offset", C.c_float * 2), ("pad", C.c_uint32 * 3)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("aggregate", C.c_uint32),
@@ -146,6 +162,11 @@ class SceneDesc(C.Structure):
         ("n_texels", C.c_uint32), ("texels", C.POINTER(C.c_uint32)),
         ("n_material_recipes", C.c_uint32), ("material_recipes", C.POINTER(MaterialRecipe)),
         ("n_bezier_patches", C.c_uint32), ("bezier_patches", C.POINTER(BezierPatch)),
+        ("n_pndfs", C.c_uint32), ("pndfs", C.POINTER(Pndf)),
+        ("n_pndf_terms", C.c_uint32), ("pndf_terms", C.POINTER(PndfTerm)),
+        ("n_pndf_nodes", C.c_uint32), ("pndf_nodes", C.POINTER(PndfNode)),
+        ("n_pndf_refs", C.c_uint32), ("pndf_refs", C.POINTER(C.c_uint32)),
+        ("n_pndf_roots", C.c_uint32), ("pndf_roots", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -302,6 +323,9 @@ class Scene:
             "image_levels": (d.image_levels, d.n_image_levels, ImageLevel), "texels": (d.texels, d.n_texels, C.c_uint32),
             "material_recipes": (d.material_recipes, d.n_material_recipes, MaterialRecipe),
             "bezier_patches": (d.bezier_patches, d.n_bezier_patches, BezierPatch),
+            "pndfs": (d.pndfs, d.n_pndfs, Pndf), "pndf_terms": (d.pndf_terms, d.n_pndf_terms, PndfTerm),
+            "pndf_nodes": (d.pndf_nodes, d.n_pndf_nodes, PndfNode), "pndf_refs": (d.pndf_refs, d.n_pndf_refs, C.c_uint32),
+            "pndf_roots": (d.pndf_roots, d.n_pndf_roots, C.c_uint32),
         }
         ptr, n, ty = table[field]
         if n == 0:

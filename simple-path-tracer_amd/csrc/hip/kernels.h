@@ -607,8 +607,8 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
                         DLightSample ls;
                         if (sample_light<kSimple, kTex, kTab>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
-                            f3 f = mat_eval(mt, wo, wi);
-                            float mpdf = mat_pdf(mt, wo, wi);
+                            f3 f = mat_eval<kSubsurface>(mt, wo, wi, &sc);
+                            float mpdf = mat_pdf<kSubsurface>(mt, wo, wi, &sc);
                             if (ls.pdf != 0.0f && spt_is_finite(ls.pdf)) {
                                 f3 li;
                                 if (ls.is_delta) {

@@ -13,10 +13,20 @@
 // material, so the kernels switch on a POD material record instead.
 #pragma once
 #include "trace.h"
+#include "../../../include/spt_pndf.h"
 
 struct DRng {
     spt_rng s;
     SPT_DEV float next() { return spt_rng_f32(&s); }
+    // Rng::gaussian_2d (src/core/rng.rs:28-42): Box-Muller, redrawing while the first number is <= 1e-6
+    SPT_DEV void gaussian_2d(float mu, float sigma, float* x, float* y) {
+        float rx, ry;
+        do { rx = next(); ry = next(); } while (!(rx > 1e-6f));
+        const float mag = sigma * spt_sqrt(-2.0f * spt_log(rx));
+        const float temp = 2.0f * SPT_PI * ry;
+        *x = mag * spt_cos(temp) + mu;
+        *y = mag * spt_sin(temp) + mu;
+    }
 };
 
 // ---- what Triangle::intersect / Sphere::intersect + Instance::intersect leave in `Intersection`
@@ -580,6 +590,38 @@ SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
         d.c1 = mk3(ld / (3.5f + 100.0f * (q2.x * q2.x)), ld / (3.5f + 100.0f * (q2.y * q2.y)), ld / (3.5f + 100.0f * (q2.z * q2.z)));
         break;
     }
+    case SPT_MAT_PNDF_CONDUCTOR:    // pndf_conductor.rs:156-196; PndfMicrofacet::new (microfacet.rs:67-95)
+    case SPT_MAT_PNDF_PLASTIC: {    // pndf_plastic.rs:163-211
+        const bool plastic = r0.x == SPT_MAT_PNDF_PLASTIC;
+        const f3 albedo = tex_color(sc, r0.y, in);
+        d.c0 = albedo;
+        if (plastic) {   // DielectricFresnel::new(ior), Diffuse::new(albedo, ior)
+            d.ior = ior;
+            d.fresnel = SPT_FRESNEL_DIELECTRIC;
+            d.substrate = SPT_SUBSTRATE_DIFFUSE;
+            float fdr = 2.0f * fresnel_moment1(1.0f / ior);
+            d.c2 = cdiv(albedo * SPT_FRAC_1_PI, ((gray(1.0f) - albedo * fdr) * ior) * ior);
+            d.bxdf = specular ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;      // the fallback without a footprint
+        } else {
+            d.fresnel = SPT_FRESNEL_SCHLICK;
+            d.bxdf = specular ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
+        }
+        if (sc.pndfs != nullptr) {
+            const spt_pndf& pd = sc.pndfs[r0.z];
+            const float ux = spt_pndf_wrap(it.uv[0] * pd.tiling[0] + pd.offset[0]), uy = spt_pndf_wrap(it.uv[1] * pd.tiling[1] + pd.offset[1]);
+            const float dxx = it.duvdx[0] * pd.tiling[0], dxy = it.duvdx[1] * pd.tiling[1];
+            const float dyx = it.duvdy[0] * pd.tiling[0], dyy = it.duvdy[1] * pd.tiling[1];
+            const float sigma_p = spt_max(spt_sqrt(dxx * dxx + dxy * dxy), spt_sqrt(dyx * dyx + dyy * dyy)) / 3.0f;
+            if (sigma_p > 0.0f) {
+                const spt_pndf_view v{&pd, sc.pndf_terms, sc.pndf_nodes, sc.pndf_refs, sc.pndf_roots};
+                const float sum = spt_pndf_uv_walk(&v, ux, uy, sigma_p, 0, 0.0f, 0.0f, nullptr);
+                d.bxdf = plastic ? SPT_BXDF_PNDF_PLASTIC : SPT_BXDF_PNDF_CONDUCTOR;
+                d.ax = ux; d.ay = uy;
+                d.c1 = mk3(1.0f / sum, sigma_p, __uint_as_float(r0.z));   // per-hit record of the two P-NDF lobes: (1 / sum, sigma_p, table)
+            }
+        }
+        break;
+    }
     default:  // pbr_specular.rs:60-92
         d.c0 = tex_color(sc, r0.y, in);
         d.c1 = tex_color(sc, r0.z, in);
@@ -593,13 +635,17 @@ SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
 SPT_DEV bool mat_is_delta(const DMat& m) {
     return m.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR || m.bxdf == SPT_BXDF_SPECULAR_DIELECTRIC || m.bxdf == SPT_BXDF_PSEUDO;
 }
+SPT_DEV float pow5(float x) { return x * x * x * x * x; }
 SPT_DEV f3 mat_fresnel(const DMat& m, f3 i, f3 n) {  // fresnel.rs:29-59
-    if (m.bxdf == SPT_BXDF_MICROFACET_CONDUCTOR || m.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR) return fresnel_conductor_n(m.c0, m.c1, i, n);
+    if (m.bxdf == SPT_BXDF_MICROFACET_CONDUCTOR || m.bxdf == SPT_BXDF_SPECULAR_CONDUCTOR || m.bxdf == SPT_BXDF_PNDF_CONDUCTOR) {
+        // the conductors of pndf_conductor.rs carry SchlickFresnel::new(albedo) (fresnel.rs:49-52)
+        if (m.fresnel == SPT_FRESNEL_SCHLICK) return m.c0 + (gray(1.0f) - m.c0) * pow5(1.0f - dot(i, n));
+        return fresnel_conductor_n(m.c0, m.c1, i, n);
+    }
     return gray(fresnel_n(m.ior, i, n));
 }
 // plastic lobes: SchlickFresnel / DielectricFresnel (fresnel.rs:19-59), Lambert / Diffuse substrate
 // (substrate.rs:29-45, 139-180)
-SPT_DEV float pow5(float x) { return x * x * x * x * x; }
 SPT_DEV f3 plastic_fresnel(const DMat& m, f3 i, f3 n) {
     if (m.fresnel == SPT_FRESNEL_SCHLICK) return m.c1 + (gray(1.0f) - m.c1) * pow5(1.0f - dot(i, n));
     return gray(fresnel_n(m.ior, i, n));
@@ -612,6 +658,46 @@ SPT_DEV f3 substrate_eval(const DMat& m, f3 wo, f3 wi) {
 }
 SPT_DEV float ndf_visible(const DMat& m, f3 wo, f3 wi, f3 h) {  // microfacet.rs:47-53
     return ggx_ndf_aniso(h, m.ax, m.ay) * smith_visible_aniso(wo, wi, m.ax, m.ay);
+}
+
+// PndfMicrofacet (src/bxdf/microfacet.rs:56-170) over the per-hit constants material_at left in the material record
+SPT_DEV spt_pndf_view pndf_view(const DScene& sc, const DMat& m) {
+    return spt_pndf_view{sc.pndfs + __float_as_uint(m.c1.z), sc.pndf_terms, sc.pndf_nodes, sc.pndf_refs, sc.pndf_roots};
+}
+SPT_DEV float pndf_half_pdf(const DScene& sc, const DMat& m, f3 half) {   // microfacet.rs:142-154
+    const spt_pndf_view v = pndf_view(sc, m);
+    return spt_pndf_calc(&v, m.c1.y, spt_pndf_term_coe(v.pd, m.c1.x), m.ax, m.ay, half.x, half.y);
+}
+SPT_DEV float pndf_ndf_visible(const DScene& sc, const DMat& m, f3 wo, f3 wi, f3 half) {   // microfacet.rs:156-169
+    const float pndf = pndf_half_pdf(sc, m, half);
+    const float visible = 0.25f / spt_max(wi.z * wo.z, 0.0001f);
+    return pndf / spt_max(half.z, 0.0001f) * visible;
+}
+SPT_DEV f3 pndf_sample_half(const DScene& sc, const DMat& m, DRng& rng, float* pdf) {   // microfacet.rs:98-140
+    const spt_pndf_view v = pndf_view(sc, m);
+    const spt_pndf& pd = *v.pd;
+    const float sigma_p = m.c1.y;
+    const float sigma_p_sqr = sigma_p * sigma_p, sigma_p_sqr_inv = 1.0f / sigma_p_sqr;
+    const float sigma_h_sqr = pd.sigma_hx * pd.sigma_hy, sigma_h_sqr_inv = 1.0f / sigma_h_sqr;
+    const float sigma_sqr_sum_inv = 1.0f / (sigma_p_sqr + sigma_h_sqr);
+    const float rand = rng.next();
+    uint32_t ti = 0xffffffffu;
+    spt_pndf_uv_walk(&v, m.ax, m.ay, sigma_p, 1, m.c1.x, rand, &ti);
+    if (ti == 0xffffffffu) ti = pd.first_term;   // no term within reach (the reference indexes an empty list there)
+    const spt_pndf_term& g = v.terms[ti];
+    const float mux = sigma_sqr_sum_inv * (sigma_h_sqr * m.ax + sigma_p_sqr * g.u[0]), muy = sigma_sqr_sum_inv * (sigma_h_sqr * m.ay + sigma_p_sqr * g.u[1]);
+    const float sigma = 1.0f / spt_sqrt(sigma_p_sqr_inv + sigma_h_sqr_inv);
+    float gx, gy;
+    rng.gaussian_2d(0.0f, sigma, &gx, &gy);
+    const float ux = mux + gx, uy = muy + gy;
+    float jx, jy;
+    spt_m2_mul(g.jacobian, ux - g.u[0], uy - g.u[1], &jx, &jy);
+    const float smx = g.s[0] + jx, smy = g.s[1] + jy;
+    rng.gaussian_2d(0.0f, pd.sigma_r, &gx, &gy);
+    const float sx = smx + gx, sy = smy + gy;
+    const f3 half = normalize(mk3(sx, sy, spt_sqrt(spt_clamp(1.0f - (sx * sx + sy * sy), 0.0f, 1.0f))));
+    *pdf = spt_pndf_calc(&v, sigma_p, spt_pndf_term_coe(v.pd, m.c1.x), m.ax, m.ay, sx, sy);
+    return half;
 }
 
 struct DBxdfSample {
@@ -727,6 +813,18 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
         s.pdf = half_pdf / (4.0f * spt_abs(dot(wo, half)));
         break;
     }
+    case SPT_BXDF_PNDF_CONDUCTOR: {  // MicrofacetConductor::sample (microfacet_conductor.rs:23-42) over a PndfMicrofacet
+        if (kSS) {
+            float half_pdf;
+            f3 half = pndf_sample_half(*sc, m, rng, &half_pdf);
+            f3 fr = mat_fresnel(m, wo, half);
+            f3 wi = reflect_n(wo, half);
+            s.wi = wi;
+            s.f = fr * pndf_ndf_visible(*sc, m, wo, wi, half);
+            s.pdf = half_pdf / (4.0f * spt_abs(dot(wo, half)));
+        }
+        break;
+    }
     case SPT_BXDF_SPECULAR_CONDUCTOR: {  // specular_conductor.rs:19-36
         f3 fr = mat_fresnel(m, wo, mk3(0, 0, 1));
         f3 wi = reflect_z(wo);
@@ -781,9 +879,11 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
         }
         break;
     }
+    case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC:
     case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:26-79, specular_plastic.rs:19-63
-        const bool rough = m.bxdf == SPT_BXDF_MICROFACET_PLASTIC;
+        const bool glint = kSS && m.bxdf == SPT_BXDF_PNDF_PLASTIC;   // the same lobe over a PndfMicrofacet
+        const bool rough = m.bxdf == SPT_BXDF_MICROFACET_PLASTIC || glint;
         f3 fresnel_macro = plastic_fresnel(m, wo, mk3(0, 0, 1));
         float specular_weight = luminance(fresnel_macro);
         float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * m.c0);
@@ -792,11 +892,17 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
             f3 wi, specular_bxdf;
             float specular_pdf;
             if (rough) {
-                float r0 = rng.next(), r1 = rng.next(), half_pdf;
-                f3 half = ggx_vndf_sample(wo, m.ax, m.ay, r0, r1, &half_pdf);
+                float half_pdf;
+                f3 half;
+                if (glint) {
+                    half = pndf_sample_half(*sc, m, rng, &half_pdf);
+                } else {
+                    float r0 = rng.next(), r1 = rng.next();
+                    half = ggx_vndf_sample(wo, m.ax, m.ay, r0, r1, &half_pdf);
+                }
                 f3 fr = plastic_fresnel(m, wo, half);
                 wi = reflect_n(wo, half);
-                specular_bxdf = fr * ndf_visible(m, wo, wi, half);
+                specular_bxdf = fr * (glint ? pndf_ndf_visible(*sc, m, wo, wi, half) : ndf_visible(m, wo, wi, half));
                 specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
             } else {
                 wi = reflect_z(wo);
@@ -834,9 +940,9 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
             float specular_pdf;
             if (rough) {
                 f3 half = half_from_reflect(wo, wi);
-                float half_pdf = ggx_vndf_pdf(half, wo, m.ax, m.ay);
+                float half_pdf = glint ? pndf_half_pdf(*sc, m, half) : ggx_vndf_pdf(half, wo, m.ax, m.ay);
                 specular_pdf = reflect_pdf * half_pdf / (4.0f * spt_abs(dot(wo, half)));
-                specular_bxdf = plastic_fresnel(m, wo, half) * ndf_visible(m, wo, wi, half);
+                specular_bxdf = plastic_fresnel(m, wo, half) * (glint ? pndf_ndf_visible(*sc, m, wo, wi, half) : ndf_visible(m, wo, wi, half));
             } else {
                 specular_pdf = reflect_pdf;
                 specular_bxdf = crcp(fresnel_macro, spt_abs(wi.z));
@@ -858,8 +964,16 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
     return s;
 }
 
-SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi) {
+// kSS (k_shade<3>): position-normal distributions can occur; sc is only touched then
+template <bool kSS = false>
+SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
     switch (m.bxdf) {
+    case SPT_BXDF_PNDF_CONDUCTOR:  // microfacet_conductor.rs:44-53
+        if (kSS && wo.z * wi.z >= 0.0f) {
+            f3 half = half_from_reflect(wo, wi);
+            return pndf_half_pdf(*sc, m, half) / (4.0f * spt_abs(dot(wo, half)));
+        }
+        return 1.0f;
     case SPT_BXDF_LAMBERT:  // lambert.rs:38-44
         return (wo.z * wi.z >= 0.0f) ? spt_abs(wi.z) * SPT_FRAC_1_PI : 1.0f;
     case SPT_BXDF_MICROFACET_CONDUCTOR:  // microfacet_conductor.rs:44-53
@@ -888,6 +1002,7 @@ SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi) {
         float reflect_pdf = luminance(mat_fresnel(m, wo, mk3(0, 0, 1)));
         return (wo.z * wi.z >= 0.0f) ? reflect_pdf : 1.0f - reflect_pdf;
     }
+    case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC:
     case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:81-99, specular_plastic.rs:65-80
         if (!(wo.z * wi.z >= 0.0f)) return 1.0f;
@@ -896,7 +1011,10 @@ SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi) {
         float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * m.c0);
         float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
         float specular_pdf;
-        if (m.bxdf == SPT_BXDF_MICROFACET_PLASTIC) {
+        if (kSS && m.bxdf == SPT_BXDF_PNDF_PLASTIC) {
+            f3 half = half_from_reflect(wo, wi);
+            specular_pdf = reflect_pdf * pndf_half_pdf(*sc, m, half) / (4.0f * spt_abs(dot(wo, half)));
+        } else if (m.bxdf == SPT_BXDF_MICROFACET_PLASTIC) {
             f3 half = half_from_reflect(wo, wi);
             specular_pdf = reflect_pdf * ggx_vndf_pdf(half, wo, m.ax, m.ay) / (4.0f * spt_abs(dot(wo, half)));
         } else {
@@ -909,8 +1027,15 @@ SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi) {
     }
 }
 
-SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi) {
+template <bool kSS = false>
+SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
     switch (m.bxdf) {
+    case SPT_BXDF_PNDF_CONDUCTOR:  // microfacet_conductor.rs:55-64
+        if (kSS && wo.z * wi.z >= 0.0f) {
+            f3 half = half_from_reflect(wo, wi);
+            return mat_fresnel(m, wo, half) * pndf_ndf_visible(*sc, m, wo, wi, half);
+        }
+        return gray(0.0f);
     case SPT_BXDF_LAMBERT:  // lambert.rs:46-52
         return (wo.z * wi.z >= 0.0f) ? m.c0 * SPT_FRAC_1_PI : gray(0.0f);
     case SPT_BXDF_MICROFACET_CONDUCTOR:  // microfacet_conductor.rs:55-64
@@ -948,10 +1073,12 @@ SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi) {
         }
         return gray(0.0f);
     }
+    case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC: {  // microfacet_plastic.rs:101-118
         if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
         f3 half = half_from_reflect(wo, wi);
-        f3 refl = plastic_fresnel(m, wo, half) * ndf_visible(m, wo, wi, half);
+        const bool glint = kSS && m.bxdf == SPT_BXDF_PNDF_PLASTIC;
+        f3 refl = plastic_fresnel(m, wo, half) * (glint ? pndf_ndf_visible(*sc, m, wo, wi, half) : ndf_visible(m, wo, wi, half));
         f3 sub = (gray(1.0f) - plastic_fresnel(m, wo, mk3(0, 0, 1))) * substrate_eval(m, wo, wi);
         return refl + sub;
     }

@@ -509,6 +509,7 @@ struct spt_scene {
     bool fused = false;     // k_shade<0, ., kFused> can run: lds_tables and a simple scene
     bool subsurface = false;  // some material has a Subsurface substrate (k_shade<3, .>)
     DeviceBuffer ss_cdf;
+    DeviceBuffer pndfs, pndf_terms, pndf_nodes, pndf_refs, pndf_roots;   // position-normal distributions (k_shade<3, .> too)
     bool textured = false;  // a material recipe, normal map or emissive map samples textures per hit (k_shade<2, .>)
     DeviceBuffer textures, tex_prog, tex_root, tex_chain, images, image_levels, texels, recipes;
     std::vector<hipEvent_t> events;
@@ -582,7 +583,7 @@ void validate(const spt_scene_desc& s) {
         if (s.surfaces[i].inside_medium >= 254) fail(SPT_ERR_UNSUPPORTED, "scene desc: more than 254 mediums");
     }
     for (uint32_t i = 0; i < s.n_materials; ++i) {
-        if (s.materials[i].bxdf > SPT_BXDF_SPECULAR_PLASTIC) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown bxdf tag");
+        if (s.materials[i].bxdf > SPT_BXDF_SPECULAR_PLASTIC) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown bxdf tag");   // SPT_BXDF_PNDF_CONDUCTOR only exists per hit
         if (s.materials[i].recipe > s.n_material_recipes) fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe out of range");
     }
     need(s.textures, s.n_textures, "textures");
@@ -612,9 +613,52 @@ void validate(const spt_scene_desc& s) {
     }
     for (uint32_t i = 0; i < s.n_material_recipes; ++i) {
         const spt_material_recipe& r = s.material_recipes[i];
-        if (r.type > SPT_MAT_SUBSURFACE || r.rough_chan > SPT_CHAN_A || r.metal_chan > SPT_CHAN_A) fail(SPT_ERR_INVALID_ARG, "scene desc: bad material recipe");
-        for (int k = 0; k < 4; ++k)
-            if (r.tex[k] >= s.n_textures) fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe texture out of range");
+        if (r.type > SPT_MAT_PNDF_PLASTIC || r.rough_chan > SPT_CHAN_A || r.metal_chan > SPT_CHAN_A) fail(SPT_ERR_INVALID_ARG, "scene desc: bad material recipe");
+        for (int k = 0; k < 4; ++k) {
+            if (r.type >= SPT_MAT_PNDF_CONDUCTOR && k == 1) {
+                if (r.tex[k] >= s.n_pndfs) fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe P-NDF out of range");
+            } else if (r.tex[k] >= s.n_textures) {
+                fail(SPT_ERR_INVALID_ARG, "scene desc: material recipe texture out of range");
+            }
+        }
+    }
+    // position-normal distributions: every index the per-hit tree walks of include/spt_pndf.h follow
+    need(s.pndfs, s.n_pndfs, "pndfs");
+    need(s.pndf_terms, s.n_pndf_terms, "pndf_terms");
+    need(s.pndf_nodes, s.n_pndf_nodes, "pndf_nodes");
+    need(s.pndf_refs, s.n_pndf_refs, "pndf_refs");
+    need(s.pndf_roots, s.n_pndf_roots, "pndf_roots");
+    for (uint32_t i = 0; i < s.n_pndf_refs; ++i)
+        if (s.pndf_refs[i] >= s.n_pndf_terms) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF term reference out of range");
+    for (uint32_t i = 0; i < s.n_pndf_nodes; ++i) {
+        const spt_pndf_node& n = s.pndf_nodes[i];
+        const bool leaf = n.lc == 0xffffffffu;
+        // children behind their parent: no walk can cycle
+        if (!leaf && (n.lc <= i || n.rc <= i || n.lc >= s.n_pndf_nodes || n.rc >= s.n_pndf_nodes)) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF node children out of order");
+        if (n.start > n.end || n.end > s.n_pndf_refs) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF node range out of bounds");
+    }
+    {
+        // the leaves' ranges are relative to their tree's first ref: one pass over every tree
+        std::vector<uint32_t> todo;
+        auto check_tree = [&](uint32_t root, uint32_t first_ref) {
+            if (root == 0xffffffffu) return;
+            if (root >= s.n_pndf_nodes || first_ref > s.n_pndf_refs) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF tree root out of range");
+            todo.assign(1, root);
+            while (!todo.empty()) {
+                const spt_pndf_node& n = s.pndf_nodes[todo.back()];
+                todo.pop_back();
+                if ((uint64_t)first_ref + n.end > s.n_pndf_refs) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF leaf range out of bounds");
+                if (n.lc != 0xffffffffu) { todo.push_back(n.lc); todo.push_back(n.rc); }
+            }
+        };
+        for (uint32_t i = 0; i < s.n_pndfs; ++i) {
+            const spt_pndf& pd = s.pndfs[i];
+            if (pd.n_terms == 0 || (uint64_t)pd.first_term + pd.n_terms > s.n_pndf_terms) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF term range out of bounds");
+            if (pd.s_block_count == 0 || pd.s_block_count > 4096u || (uint64_t)pd.first_root + 2ull * pd.s_block_count * pd.s_block_count > s.n_pndf_roots)
+                fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF block table out of bounds");
+            for (uint32_t b = 0; b < pd.s_block_count * pd.s_block_count; ++b) check_tree(s.pndf_roots[pd.first_root + 2u * b], s.pndf_roots[pd.first_root + 2u * b + 1u]);
+            check_tree(pd.uv_root, pd.uv_first_ref);
+        }
     }
     for (uint32_t i = 0; i < s.n_surfaces; ++i)
         if (s.surfaces[i].normal_map > s.n_textures || s.surfaces[i].emissive_map > s.n_textures)
@@ -990,6 +1034,19 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         for (uint32_t i = 0; i < s.n_surfaces; ++i) textured = textured || s.surfaces[i].normal_map != 0 || s.surfaces[i].emissive_map != 0;
         for (uint32_t i = 0; i < s.n_materials; ++i) sc->subsurface = sc->subsurface || s.materials[i].substrate == SPT_SUBSTRATE_SUBSURFACE;
         for (uint32_t i = 0; i < s.n_material_recipes; ++i) sc->subsurface = sc->subsurface || s.material_recipes[i].type == SPT_MAT_SUBSURFACE;
+        if (s.n_pndfs != 0) {   // glints ride in the heavy variant too: their tree walks would cost k_shade<2> its registers
+            sc->subsurface = true;
+            sc->pndfs.upload(s.pndfs, s.n_pndfs);
+            sc->pndf_terms.upload(s.pndf_terms, s.n_pndf_terms);
+            sc->pndf_nodes.upload(s.pndf_nodes, s.n_pndf_nodes);
+            sc->pndf_refs.upload(s.pndf_refs, s.n_pndf_refs);
+            sc->pndf_roots.upload(s.pndf_roots, s.n_pndf_roots);
+            d.pndfs = sc->pndfs.as<spt_pndf>();
+            d.pndf_terms = sc->pndf_terms.as<spt_pndf_term>();
+            d.pndf_nodes = sc->pndf_nodes.as<spt_pndf_node>();
+            d.pndf_refs = sc->pndf_refs.as<uint32_t>();
+            d.pndf_roots = sc->pndf_roots.as<uint32_t>();
+        }
         if (sc->subsurface) {
             textured = true;   // k_shade<3> is k_shade<2> + the probe: the texture tables (possibly empty) are uploaded below
             std::vector<float2> cdf(SPT_SS_CDF_SIZE);

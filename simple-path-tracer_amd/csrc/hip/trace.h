@@ -70,6 +70,12 @@ struct DScene {
     const uint32_t* texels;        // RGBA8
     const uint4* recipes;          // 2 x uint4 per spt_material_recipe
     const float2* ss_cdf;          // SPT_SS_CDF_SIZE x (x, y): BSSRDF radius table (scenes with a Subsurface substrate)
+    // position-normal distributions (include/spt_pndf.h; k_shade<3, .> only, null otherwise)
+    const spt_pndf* pndfs;
+    const spt_pndf_term* pndf_terms;
+    const spt_pndf_node* pndf_nodes;
+    const uint32_t* pndf_refs;
+    const uint32_t* pndf_roots;
 };
 
 struct DHit {

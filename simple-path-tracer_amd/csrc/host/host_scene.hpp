@@ -24,6 +24,10 @@ struct HostScene {
     std::vector<spt_tri_attr> tri_attr;
     std::vector<spt_sphere> spheres;
     std::vector<spt_bezier_patch> bezier_patches;
+    std::vector<spt_pndf> pndfs;                 // position-normal distributions (pndf.cpp)
+    std::vector<spt_pndf_term> pndf_terms;
+    std::vector<spt_pndf_node> pndf_nodes;
+    std::vector<uint32_t> pndf_refs, pndf_roots;
     std::vector<spt_surface> surfaces;
     std::vector<spt_material> materials;
     std::vector<spt_medium> mediums;
@@ -48,6 +52,8 @@ struct HostScene {
 };
 
 HostScene* load_scene_file(const std::string& path);
+// pndf.cpp: the Gaussian terms and trees of one pndf_conductor material (PndfConductor::new), appended to the scene
+uint32_t build_pndf(HostScene& hs, uint32_t base_normal_texture, float sigma_r, float h, const std::string& label);
 // catmull.cpp: 16 control points (x, y, z) per bicubic patch of the Catmull-Clark surface of an ASCII PLY control mesh
 std::vector<float> catmull_clark_patches(const std::string& ply_path, uint32_t fas_times);
 void read_png_rgba8(const std::string& path, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);

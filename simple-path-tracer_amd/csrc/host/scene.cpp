@@ -743,9 +743,50 @@ struct SceneBuilder {
                 m.c1[k] = ld / (3.5f + 100.0f * (q2 * q2));
             }
         } else if (ty == "pndf_conductor" || ty == "pndf_plastic") {
+            // PndfConductor::load / ::new (src/material/pndf_conductor.rs:31-154), PndfPlastic (pndf_plastic.rs:30-161).
+            // The constants of `m` are the fallback the material takes when a hit has no pixel footprint
+            // (pndf_conductor.rs:181-194, pndf_plastic.rs:188-209) at the textures' averages; the recipe below is what
+            // every hit evaluates
+            const bool plastic = ty == "pndf_plastic";
+            float ior = 0.0f;
+            if (plastic) {
+                const float int_ior = p.get_float("int_ior");
+                ior = int_ior / p.get_float_or("ext_ior", 1.0f);
+            }
+            V3 albedo = texture(p.get_str("albedo"));
+            const float fr = texture(p.get_str("fallback_roughness")).x;
+            m.ax = m.ay = fr * fr;
+            m.c0[0] = albedo.x; m.c0[1] = albedo.y; m.c0[2] = albedo.z;
+            if (plastic) {
+                m.ior = ior;
+                m.bxdf = (m.ax < 0.0001f) ? SPT_BXDF_SPECULAR_PLASTIC : SPT_BXDF_MICROFACET_PLASTIC;
+                m.fresnel = SPT_FRESNEL_DIELECTRIC;
+                m.substrate = SPT_SUBSTRATE_DIFFUSE;
+                const float fdr = 2.0f * fresnel_moment1(1.0f / m.ior);   // Diffuse::new (src/bxdf/substrate.rs:127-137)
+                const V3 num = albedo * 0.318309886183790671538f;
+                const V3 den = ((V3{1, 1, 1} - albedo * fdr) * m.ior) * m.ior;
+                m.c2[0] = num.x / den.x; m.c2[1] = num.y / den.y; m.c2[2] = num.z / den.z;
+            } else {
+                m.bxdf = (m.ax < 0.0001f) ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
+                m.fresnel = SPT_FRESNEL_SCHLICK;
+            }
+            spt_material_recipe r;
+            std::memset(&r, 0, sizeof r);
+            r.type = plastic ? SPT_MAT_PNDF_PLASTIC : SPT_MAT_PNDF_CONDUCTOR;
+            r.ior = ior;
+            r.tex[0] = tex_info(p.get_str("albedo")).node;
+            r.tex[1] = build_pndf(hs, tex_info(p.get_str("base_normal")).node, p.get_float("sigma_r"), p.get_float("h"), p.name());
+            r.tex[2] = tex_info(p.get_str("fallback_roughness")).node;
+            r.tex[3] = r.tex[2];
+            r.rough_chan = SPT_CHAN_R;
+            hs.material_recipes.push_back(r);
+            m.recipe = (uint32_t)hs.material_recipes.size();
+            any_textured = true;
             if (materials.count(name) || unsupported_materials.count(name)) throw HostError(SPT_HOST_ERR_SCHEMA, "Duplicated material name '" + name + "'");
-            unsupported_materials[name] = p.name() + ": material type '" + ty + "' is outside the hot-path scope (SURVEY 8f)";
-            return;   // its keys are not inspected: no unused-key warnings for a material that is not built
+            materials[name] = (uint32_t)hs.materials.size();
+            hs.materials.push_back(m);
+            p.check_unused();
+            return;
         } else {
             throw HostError(SPT_HOST_ERR_SCHEMA, p.name() + ": unknown type '" + ty + "'");
         }
@@ -1682,6 +1723,11 @@ void HostScene::finalize_desc() {
     desc.n_tris = (uint32_t)tri_pos.size(); desc.tri_pos = tri_pos.data(); desc.tri_attr = tri_attr.data();
     desc.n_spheres = (uint32_t)spheres.size(); desc.spheres = spheres.data();
     desc.n_bezier_patches = (uint32_t)bezier_patches.size(); desc.bezier_patches = bezier_patches.data();
+    desc.n_pndfs = (uint32_t)pndfs.size(); desc.pndfs = pndfs.data();
+    desc.n_pndf_terms = (uint32_t)pndf_terms.size(); desc.pndf_terms = pndf_terms.data();
+    desc.n_pndf_nodes = (uint32_t)pndf_nodes.size(); desc.pndf_nodes = pndf_nodes.data();
+    desc.n_pndf_refs = (uint32_t)pndf_refs.size(); desc.pndf_refs = pndf_refs.data();
+    desc.n_pndf_roots = (uint32_t)pndf_roots.size(); desc.pndf_roots = pndf_roots.data();
     desc.n_surfaces = (uint32_t)surfaces.size(); desc.surfaces = surfaces.data();
     desc.n_materials = (uint32_t)materials.size(); desc.materials = materials.data();
     desc.n_mediums = (uint32_t)mediums.size(); desc.mediums = mediums.data();

@@ -103,6 +103,12 @@ def oracle_lib():
         lib.oracle_ss_sample_r.restype = C.c_float
         lib.oracle_ss_cdf.argtypes = [C.c_uint32, C.c_float * 2]
         lib.oracle_ss_cdf.restype = None
+        lib.oracle_pndf_sum.argtypes = [C.POINTER(spt.SceneDesc), C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.oracle_pndf_sum.restype = None
+        lib.oracle_pndf_calc.argtypes = [C.POINTER(spt.SceneDesc), C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_pndf_calc.restype = None
+        lib.oracle_pndf_sample_half.argtypes = [C.POINTER(spt.SceneDesc), C.c_uint32, C.c_float, C.c_float * 2, C.c_uint64, C.c_uint32, C.c_void_p]
+        lib.oracle_pndf_sample_half.restype = None
         _oracle = lib
     return _oracle
 

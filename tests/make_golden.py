@@ -23,6 +23,7 @@ CASES = [  # name, scene, camera, sampler, spp, (w, h), seed, box filter radius
     ("film_t_subsurface", "t_subsurface.json", None, "random", 16, (64, 48), 1, 0.5),
     ("film_t_bezier", "t_bezier.json", "main", "random", 16, (64, 48), 1, 0.5),          # CubicBezier patches (bezier.rs)
     ("film_t_catmull", "t_catmull.json", "main", "random", 16, (64, 48), 1, 0.5),        # Catmull-Clark surfaces as Bezier patch instances (catmull.rs)
+    ("film_t_pndf", "t_pndf.json", "main", "random", 16, (64, 48), 1, 0.5),              # P-NDF glints (pndf_conductor.rs, pndf_plastic.rs)
     ("film_cfg2_cube_box1p2", "cfg2_cube.json", None, "random", 8, (64, 64), 1, 1.2),   # film.rs:71-92 with radius_int = 1
 ]
 

@@ -28,7 +28,7 @@ def _scene(spt, name):
     return spt.load_scene(os.path.join(_util.SCENES, name))
 
 
-@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json", "t_gltf.gltf", "t_subsurface.json", "t_bezier.json"])
+@pytest.mark.parametrize("scene_name", ["cfg1_sphere.json", "cfg2_cube.json", "t_materials.json", "t_power_is.json", "t_medium.json", "t_plastic.json", "t_textured.json", "t_gltf.gltf", "t_subsurface.json", "t_bezier.json", "t_pndf.json"])
 def test_trace_closest_and_any_bit_exact(spt, scene_name):
     sc = _scene(spt, scene_name)
     rays = _util.random_rays(sc, 200_000, seed=11)
@@ -100,6 +100,8 @@ def test_render_matches_oracle(spt, scene_name, size, spp, sampler):
     ("t_bezier.json", "low", "recurrence"),      #   both sides, a medium boundary on a patch (its light samples probe the patch)
     ("t_catmull.json", "main", "random"),        # Catmull-Clark surfaces: 608 patch instances (regular + Gregory patches, creases, an open
     ("t_catmull.json", "side", "recurrence"),    #   tube) under the TLAS, far beyond LDS: the large-scene kernels of libspt_hip_bez.so
+    ("t_pndf.json", "main", "random"),           # position-normal distributions (glints): conductor + plastic lobes, three tables, the GGX
+    ("t_pndf.json", "graze", "recurrence"),      #   fallback on every bounce without a pixel footprint, Gaussian draws (Box-Muller)
 ])
 def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     sc = _scene(spt, scene_name)
