@@ -21,7 +21,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("SPT_LIB_DIR") or os.path.join(_HERE, "lib")   # (SPT_LIB_DIR: A/B runs against another build, tools/ only)
 REPO_ROOT = os.path.dirname(_HERE)
 
 SPT_ABI_VERSION = 10

@@ -20,6 +20,18 @@ SPT_DEV v2 operator-(v2 a, v2 b) { return {a.x - b.x, a.y - b.y}; }
 SPT_DEV v2 operator*(v2 a, float s) { return {a.x * s, a.y * s}; }
 SPT_DEV v2 operator/(v2 a, float s) { return {a.x / s, a.y / s}; }
 SPT_DEV v2 normalize2(v2 a) { return a * (1.0f / spt_sqrt(a.x * a.x + a.y * a.y)); }
+// x / 3.0f, correctly rounded, without the division sequence (24 of the 44 divisions of one clipping call divide by 3):
+// q = x * rn(1/3), one fma for the exact residual, one for the correction.  Checked against x / 3.0f for ALL 2^32 bit
+// patterns on the host (tools/check_div3.c): identical except for -0 (gives +0) and the infinities (NaN), which are
+// passed through here.
+SPT_DEV float div3(float x) {
+    const float r = 0x1.555556p-2f;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-3.0f, q, x);
+    const float res = __builtin_fmaf(e, r, q);
+    return (x == 0.0f || spt_abs(x) == spt_inf()) ? x : res;
+}
+SPT_DEV v2 div3(v2 a) { return {div3(a.x), div3(a.y)}; }
 
 constexpr uint32_t kClippingMaxTimes = 16;   // bezier.rs:14-17
 constexpr float kClippingEps = 0.00001f;
@@ -69,7 +81,7 @@ SPT_DEV void clip_bezier_by(const v2* pt, float u_min, float u_max, v2* out) {  
     cubic_bezier_du_at(u_max, b);
     v2 d_max = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
     d_max = d_max * (u_max - u_min);
-    out[0] = p_min; out[1] = p_min + d_min / 3.0f; out[2] = p_max - d_max / 3.0f; out[3] = p_max;
+    out[0] = p_min; out[1] = p_min + div3(d_min); out[2] = p_max - div3(d_max); out[3] = p_max;
 }
 SPT_DEV void clip_bezier_at_midpoint(const v2* pt, v2* l, v2* r) {                // bezier.rs:458-485
     float b[4];
@@ -77,7 +89,7 @@ SPT_DEV void clip_bezier_at_midpoint(const v2* pt, v2* l, v2* r) {              
     const v2 p_mid = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
     cubic_bezier_du_at(0.5f, b);
     v2 d_mid = ((pt[0] * b[0] + pt[1] * b[1]) + pt[2] * b[2]) + pt[3] * b[3];
-    d_mid = d_mid * 0.5f / 3.0f;
+    d_mid = div3(d_mid * 0.5f);
     l[0] = pt[0]; l[1] = (pt[0] + pt[1]) * 0.5f; l[2] = p_mid - d_mid; l[3] = p_mid;
     r[0] = p_mid; r[1] = p_mid + d_mid; r[2] = (pt[2] + pt[3]) * 0.5f; r[3] = pt[3];
 }

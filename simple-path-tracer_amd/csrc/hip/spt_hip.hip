@@ -990,6 +990,9 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             assemble(false);
             sc->lds_geo = blob.size() * 16 <= 32u * 1024u && stack_bytes + blob.size() * 16 <= 64u * 1024u;
             if (std::getenv("SPT_NO_LDS_GEO")) sc->lds_geo = false;   // tests: drive small scenes through the large-scene path
+            // patches: the streaming walkers of the large-scene path refill lanes whose patch test is over (measured,
+            // t_bezier.json 512^2 @ 64 spp: 177 ms LDS-resident nested walkers, 147 ms here; SPT_BEZ_LDS=1 for the former)
+            if (SPT_WITH_BEZIER && std::getenv("SPT_BEZ_LDS") == nullptr) sc->lds_geo = false;
             if (!sc->lds_geo) assemble(true);
             // fused bounces (k_shade<0, ., kFused>): LDS-resident geometry + the lean simple-scene shade kernel, and
             // the shading tables must fit behind the geometry too (see tab_ld in shading.h)
@@ -1448,7 +1451,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 // which kernel classes the streaming walker serves (1 primary, 2 shadow, 4 extend).  Measured on cfg5, one box
                 // (gpurun_out r2j): extension rays 93.5 ms refilling state machine -> 87.4 ms streaming if-if; primary rays
                 // 8.8 -> 12.4 ms and shadow rays 9.8 -> 11.3 ms (coherent / short walks: the state machine's tighter loop wins)
-                const uint32_t stream_mask = env_u32("SPT_STREAM_MASK", 4u);
+                const uint32_t stream_mask = env_u32("SPT_STREAM_MASK", SPT_WITH_BEZIER ? 6u : 4u);   // (patch scenes: shadow rays too, 214 -> 197 ms on t_catmull.json)
                 const bool stream_p = stream && (stream_mask & 1u), stream_s = stream && (stream_mask & 2u), stream_e = stream && (stream_mask & 4u);
                 // kind-sorted traversal (wst.h) for the shadow / extension rays: 1 shadow, 2 extend
                 // (opt-in experiment, see DESIGN.md: its barrier-synchronous rounds are latency-starved - 180 - 215 ms vs 94)
