@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes_amd", "cfg2_cube.json"))
     ap.add_argument("--renderer", default=os.path.join(ROOT, "scenes_amd", "pt.json"))
     ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--sync-steps", action="store_true", help="timed steps wait for their film one by one (no copy / compute overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (weak scaling, configs[2], other_configs)")
@@ -206,12 +207,12 @@ def main():
         kernel_ms = np.zeros(spt.N_KERNELS)
         kernel_launches = np.zeros(spt.N_KERNELS, dtype=np.int64)
 
-        def step(profiled):
+        def step(profiled, wait=True):
             # N > 1: this rank's strips are DMA-ed straight into the node's shared-memory film (no collective, no host-side
             # scatter); N = 1: the pinned shard buffer is the image
             renderer.render_shard(sc, cfg, device=local_rank, shard_index=rank, shard_count=world, strip_rows=strip_rows,
                                   samples_per_pass=args.samples_per_pass, profile=profiled, reuse_output=True,
-                                  film=film.film if film is not None else None)
+                                  film=film.film if film is not None else None, wait=wait)
             st = renderer.last_stats
             if profiled:
                 for k in range(spt.N_KERNELS):
@@ -219,15 +220,20 @@ def main():
                     kernel_launches[k] += st.kernel_launches[k]
             return st
 
+        st = None
         for _ in range(warmup):
-            step(False)
+            st = step(False)      # (synchronous: these also deliver the counters of the bench line, every step is the same work)
         barrier()
         t0 = time.perf_counter()
-        st = None
+        # the timed steps are queued back to back (SPT_RENDER_ASYNC): step k's film leaves over PCIe on the copy stream while
+        # step k + 1's kernels run; every film has arrived in host memory when wait() returns, before the closing barrier
         for _ in range(steps):
-            st = step(False)
+            step(False, wait=args.sync_steps)
+        renderer.wait(sc, device=local_rank)
         barrier()
         dt = time.perf_counter() - t0
+        if st is None:
+            st = step(False)      # --warmup 0: the counters from one untimed step
         for _ in range(profile_steps):
             step(True)
         if profile_steps:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 10
+#define SPT_ABI_VERSION 11
 
 typedef int32_t spt_status;
 enum {
@@ -352,8 +352,14 @@ typedef struct spt_render_params {
 enum {
     SPT_RENDER_PROFILE = 1u,       /* time each kernel class with HIP events */
     SPT_RENDER_BOX_RADIUS = 2u,    /* filter_radius is set */
-    SPT_RENDER_COUNT_VISITS = 4u   /* count BVH node / triangle / instance visits on the device (stats->*_visits); the counting
+    SPT_RENDER_COUNT_VISITS = 4u,  /* count BVH node / triangle / instance visits on the device (stats->*_visits); the counting
                                       kernels are separate instantiations, slower by a few per cent: measurement runs only */
+    SPT_RENDER_ASYNC = 8u          /* ABI v11: return as soon as the work is queued.  The film's device-to-host copy runs on a
+                                      copy stream of its own, so it overlaps the kernels of the NEXT spt_render on this scene
+                                      (a caller that renders frame after frame pays max(kernels, copy) per frame instead of the
+                                      sum).  rgb_mean_out (page-locked, or the copy is not asynchronous) is valid after
+                                      spt_render_wait or after a later synchronous spt_render on the scene returns; `stats`
+                                      must be NULL (counters would need the device to be idle) */
 };
 
 #define SPT_N_KERNELS 7
@@ -408,6 +414,8 @@ void spt_scene_destroy(spt_scene* scene);
  * over the number of those samples whose offset lies within `radius`), row 0 = top.  Synchronous. */
 spt_status spt_render(const spt_scene* scene, const spt_camera* cam, const spt_render_params* params,
                       float* rgb_mean_out, spt_render_stats* stats /* may be NULL */);
+/* Blocks until every spt_render queued on the scene with SPT_RENDER_ASYNC has delivered its film (ABI v11). */
+spt_status spt_render_wait(const spt_scene* scene);
 /* Number of image rows spt_render writes for these params. */
 spt_status spt_shard_rows(const spt_render_params* params, uint32_t* rows);
 

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("SPT_LIB_DIR") or os.path.join(_HERE, "lib")   # (SPT_LIB_DIR: A/B runs against another build, tools/ only)
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 10
+SPT_ABI_VERSION = 11
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -179,6 +179,7 @@ SAMPLER_RANDOM, SAMPLER_JITTERED, SAMPLER_RECURRENCE = 0, 1, 2
 RENDER_PROFILE = 1
 RENDER_BOX_RADIUS = 2
 RENDER_COUNT_VISITS = 4
+RENDER_ASYNC = 8
 N_KERNELS = 7
 KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other", "shade_first")
 
@@ -261,6 +262,7 @@ def hip_lib() -> C.CDLL:
         lib.spt_scene_destroy.restype = None
         lib.spt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
                                    C.POINTER(RenderStats)]
+        lib.spt_render_wait.argtypes = [C.c_void_p]
         lib.spt_shard_rows.argtypes = [C.POINTER(RenderParams), C.POINTER(C.c_uint32)]
         lib.spt_trace_closest.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.spt_trace_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -456,15 +458,17 @@ class PathTracer:
     def render_shard(self, scene: Scene, config: OutputConfig, device: int = 0, shard_index: int = 0,
                      shard_count: int = 1, strip_rows: int = 16, samples_per_pass: int = 0,
                      profile: bool = False, reuse_output: bool = False, film: Optional[np.ndarray] = None,
-                     count_visits: bool = False) -> np.ndarray:
+                     count_visits: bool = False, wait: bool = True) -> np.ndarray:
         """Mean radiance of this shard's rows, shape (rows, width, 3) f32, via the HIP path.
         reuse_output=True returns a page-locked buffer owned by the device scene that the next call
         with the same shape overwrites (no per-call allocation, DMA-speed copy-out).
-        count_visits=True runs the counting instantiations of the traversal kernels (last_stats.node_visits, ...)."""
+        count_visits=True runs the counting instantiations of the traversal kernels (last_stats.node_visits, ...).
+        wait=False (SPT_RENDER_ASYNC): returns once the work is queued; the returned buffer is valid after `self.wait(scene)`
+        or after a later wait=True call on the scene; no stats (last_stats keeps the previous synchronous call's)."""
         ds = scene.device_scene(device)
         cam = scene.get_camera(config.used_camera_name)
         p = self.params(config.width, config.height, shard_index, shard_count, strip_rows, samples_per_pass,
-                        (RENDER_PROFILE if profile else 0) | (RENDER_COUNT_VISITS if count_visits else 0))
+                        (RENDER_PROFILE if profile else 0) | (RENDER_COUNT_VISITS if count_visits else 0) | (0 if wait else RENDER_ASYNC))
         rows = C.c_uint32()
         _check_hip(hip_lib().spt_shard_rows(C.byref(p), C.byref(rows)))
         if film is not None:
@@ -474,17 +478,23 @@ class PathTracer:
             p.out_strip_stride = shard_count * strip_rows * row_bytes
             stats = RenderStats()
             first = film.ctypes.data + shard_index * strip_rows * row_bytes
-            _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), first if rows.value else film.ctypes.data, C.byref(stats)))
-            self.last_stats = stats
+            _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), first if rows.value else film.ctypes.data, C.byref(stats) if wait else None))
+            if wait:
+                self.last_stats = stats
             return film
         if reuse_output and rows.value:
             out = ds.film_buffer(rows.value, config.width)
         else:
             out = np.zeros((rows.value, config.width, 3), dtype=np.float32)
         stats = RenderStats()
-        _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(stats)))
-        self.last_stats = stats
+        _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(stats) if wait else None))
+        if wait:
+            self.last_stats = stats
         return out
+
+    def wait(self, scene: Scene, device: int = 0) -> None:
+        """spt_render_wait: every render_shard(..., wait=False) queued on the scene has delivered its film."""
+        _check_hip(hip_lib().spt_render_wait(scene.device_scene(device)._h))
 
     def render(self, scene: Scene, config: OutputConfig, device: int = 0) -> np.ndarray:
         """RendererT::render (src/renderer/pt.rs:237-296): full image on one GPU; writes the PNG

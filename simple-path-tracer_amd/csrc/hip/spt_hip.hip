@@ -479,6 +479,7 @@ struct BezierLib {
     spt_status (*create)(const spt_scene_desc*, int32_t, spt_scene**) = nullptr;
     void (*destroy)(spt_scene*) = nullptr;
     spt_status (*render)(const spt_scene*, const spt_camera*, const spt_render_params*, float*, spt_render_stats*) = nullptr;
+    spt_status (*render_wait)(const spt_scene*) = nullptr;
     spt_status (*trace_closest)(const spt_scene*, uint32_t, const spt_ray*, spt_hit*) = nullptr;
     spt_status (*trace_any)(const spt_scene*, uint32_t, const spt_ray*, uint8_t*) = nullptr;
     const char* (*last_error)(void) = nullptr;
@@ -491,6 +492,9 @@ struct spt_scene {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: k_shadow(b) next to k_extend(b) (see spt_render)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream_copy = nullptr;        // SPT_RENDER_ASYNC: the film's D2H copy, next to the following render's kernels
+    hipEvent_t ev_out_ready = nullptr, ev_copy_done = nullptr;
+    bool copy_pending = false;                // an asynchronous copy-out of `out` may still be in flight
     DScene d{};
     DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, bezier, surfaces, materials, mediums, lights;
     DeviceBuffer light_props, light_u, light_k, env_px, env_uk, geo;
@@ -519,6 +523,9 @@ struct spt_scene {
         for (auto e : events) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_out_ready) (void)hipEventDestroy(ev_out_ready);
+        if (ev_copy_done) (void)hipEventDestroy(ev_copy_done);
+        if (stream_copy) (void)hipStreamDestroy(stream_copy);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -723,11 +730,12 @@ const BezierLib* bezier_lib() {
         lib.create = reinterpret_cast<decltype(lib.create)>(dlsym(h, "spt_scene_create"));
         lib.destroy = reinterpret_cast<decltype(lib.destroy)>(dlsym(h, "spt_scene_destroy"));
         lib.render = reinterpret_cast<decltype(lib.render)>(dlsym(h, "spt_render"));
+        lib.render_wait = reinterpret_cast<decltype(lib.render_wait)>(dlsym(h, "spt_render_wait"));
         lib.trace_closest = reinterpret_cast<decltype(lib.trace_closest)>(dlsym(h, "spt_trace_closest"));
         lib.trace_any = reinterpret_cast<decltype(lib.trace_any)>(dlsym(h, "spt_trace_any"));
         lib.last_error = reinterpret_cast<decltype(lib.last_error)>(dlsym(h, "spt_last_error"));
         auto version = reinterpret_cast<uint32_t (*)(void)>(dlsym(h, "spt_abi_version"));
-        if (!lib.create || !lib.destroy || !lib.render || !lib.trace_closest || !lib.trace_any || !lib.last_error || !version || version() != SPT_ABI_VERSION) {
+        if (!lib.create || !lib.destroy || !lib.render || !lib.render_wait || !lib.trace_closest || !lib.trace_any || !lib.last_error || !version || version() != SPT_ABI_VERSION) {
             err = path + " does not export ABI version " + std::to_string(SPT_ABI_VERSION);
             return;
         }
@@ -790,6 +798,9 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         sc->device = device;
         HIP_CHECK(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&sc->stream_copy, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&sc->ev_out_ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sc->ev_copy_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
         const spt_scene_desc& s = *desc;
@@ -1167,6 +1178,7 @@ void spt_scene_destroy(spt_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     (void)hipStreamSynchronize(scene->stream);
+    if (scene->stream_copy) (void)hipStreamSynchronize(scene->stream_copy);
     // every DeviceBuffer member frees itself (a list here used to miss the buffers added later)
     delete scene;
 }
@@ -1193,6 +1205,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         if ((uint64_t)p.width * p.height > 0xffffffffull) fail(SPT_ERR_UNSUPPORTED, "render: more than 2^32 pixels");
         const uint32_t own_rows = shard_row_count(p);
         const uint64_t own_pix64 = (uint64_t)own_rows * p.width;
+        const bool async_out = (p.flags & SPT_RENDER_ASYNC) != 0;
+        if (async_out && (stats || (p.flags & (SPT_RENDER_PROFILE | SPT_RENDER_COUNT_VISITS))))
+            fail(SPT_ERR_INVALID_ARG, "render: SPT_RENDER_ASYNC returns no stats (stats must be NULL, no PROFILE / COUNT_VISITS)");
         // `stats` belongs to a caller that may have been compiled against an older (shorter) spt_render_stats: fill a
         // local copy and hand back only the bytes the caller says it has (spt_render_params::stats_size, ABI v9)
         spt_render_stats* const stats_out = stats;
@@ -1580,6 +1595,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             const RenderCtx rc = trace_window(0, own_rows, p.shard_index, shard_count, strip_rows, false);
             begin(SPT_K_RESOLVE);
             const dim3 grid((own_pix + kBlock - 1) / kBlock);
+            if (sc->copy_pending) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_copy_done, 0));   // the previous frame's copy-out reads `out`
             if (radius == 0.5f) hipLaunchKernelGGL(k_finish, dim3((own_pix * 3 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, sc->out.as<float>());
             else hipLaunchKernelGGL(k_finish_box, grid, dim3(kBlock), 0, st, rc, sc->out.as<float>(), radius, R);
             end();
@@ -1604,13 +1620,21 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 const RenderCtx rc = trace_window(b0, b1 - b0, 0u, 1u, 1u, true);
                 begin(SPT_K_RESOLVE);
                 BoxJob job{sc->rad.as<float>(), b0, b1 - b0, j0, j1 - j0, sc->out.as<float>() + k * (size_t)p.width * 3, R, radius};
+                if (sc->copy_pending) HIP_CHECK(hipStreamWaitEvent(st, sc->ev_copy_done, 0));
                 hipLaunchKernelGGL(k_filter_box, dim3(((j1 - j0) * p.width + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc, job);
                 end();
                 k = e;
             }
         }
         HIP_CHECK(hipGetLastError());
+        hipStream_t st_out = st;
+        if (async_out) {   // the copy-out leaves the compute stream: the next render's kernels run beside it
+            HIP_CHECK(hipEventRecord(sc->ev_out_ready, st));
+            HIP_CHECK(hipStreamWaitEvent(sc->stream_copy, sc->ev_out_ready, 0));
+            st_out = sc->stream_copy;
+        }
         {
+            hipStream_t st = st_out;
             const size_t strip_bytes = (size_t)strip_rows * p.width * 3 * sizeof(float);
             if (p.out_strip_stride == 0 || p.out_strip_stride == strip_bytes) {
                 HIP_CHECK(hipMemcpyAsync(rgb_mean_out, sc->out.p, (size_t)own_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1625,10 +1649,16 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                                              rest_rows * (size_t)p.width * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
             }
         }
+        if (async_out) {
+            HIP_CHECK(hipEventRecord(sc->ev_copy_done, sc->stream_copy));
+            sc->copy_pending = true;
+            return SPT_OK;
+        }
         unsigned long long h_visits[12] = {};
         if (count) HIP_CHECK(hipMemcpyAsync(h_visits, sc->visits.p, sizeof h_visits, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(ev_total1, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        sc->copy_pending = false;   // (the finish kernels of this render waited for any copy-out still in flight)
         if (stats) {
             for (int c = 0; c < 3; ++c)
                 for (int k = 0; k < 3; ++k) stats->class_visits[c][k] = h_visits[3 * c + k];
@@ -1663,6 +1693,27 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
     } catch (const std::exception& e) {
         g_error = std::string("render: ") + e.what();
         return SPT_ERR_OUT_OF_MEMORY;
+    }
+}
+
+spt_status spt_render_wait(const spt_scene* scene_c) {
+    if (!scene_c) { g_error = "render_wait: null argument"; return SPT_ERR_INVALID_ARG; }
+    spt_scene* sc = const_cast<spt_scene*>(scene_c);
+    if (sc->fwd) {
+        const spt_status st = sc->fwd->render_wait(sc->inner);
+        if (st != SPT_OK) g_error = sc->fwd->last_error();
+        return st;
+    }
+    std::lock_guard<std::mutex> lock(sc->mu);
+    try {
+        HIP_CHECK(hipSetDevice(sc->device));
+        HIP_CHECK(hipStreamSynchronize(sc->stream));
+        HIP_CHECK(hipStreamSynchronize(sc->stream_copy));
+        sc->copy_pending = false;
+        return SPT_OK;
+    } catch (const AbiError& e) {
+        g_error = e.msg;
+        return e.code;
     }
 }
 

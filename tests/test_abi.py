@@ -160,3 +160,43 @@ def test_product_sources_never_reference_the_oracle():
     assert not bad, bad
     nm = subprocess.run(["nm", "-D", os.path.join(spt.LIB_DIR, "libspt_host.so")], capture_output=True, text=True).stdout
     assert "oracle_" not in nm
+
+
+@pytest.mark.gpu
+def test_async_render_delivers_the_same_film_after_wait():
+    """SPT_RENDER_ASYNC (ABI v11): frames queued back to back, each film copied out next to the following frame's kernels;
+    after spt_render_wait the buffer holds the last frame, bit-identical to a synchronous render; stats are refused."""
+    sc = spt.load_scene(os.path.join(_util.SCENES, "cfg2_cube.json"))
+    bz = spt.load_scene(os.path.join(_util.SCENES, "t_bezier.json"))          # forwarded to libspt_hip_bez.so
+    for scene, cam in ((sc, None), (bz, "main")):
+        cfg = spt.OutputConfig(96, 80, None, cam)
+        want = {seed: spt.PathTracer(max_depth=6, spp=8, seed=seed).render_shard(scene, cfg).copy() for seed in (3, 4)}
+        r = spt.PathTracer(max_depth=6, spp=8, seed=3)
+        buf = r.render_shard(scene, cfg, reuse_output=True)                  # synchronous: allocates the pinned buffer
+        for seed in (3, 4, 3, 4):
+            r.seed = seed
+            out = r.render_shard(scene, cfg, reuse_output=True, wait=False)
+            assert out.ctypes.data == buf.ctypes.data
+        r.wait(scene)
+        assert np.array_equal(out.view(np.uint32), want[4].view(np.uint32))
+        # a synchronous render after asynchronous ones: ordered behind their copies
+        r.seed = 3
+        r.render_shard(scene, cfg, reuse_output=True, wait=False)
+        r.seed = 4
+        r.render_shard(scene, cfg, reuse_output=True, wait=False)
+        r.seed = 3
+        got = r.render_shard(scene, cfg, reuse_output=True)
+        assert np.array_equal(got.view(np.uint32), want[3].view(np.uint32))
+        # different shard shapes in flight one after the other (strided copies into a full-image film)
+        film = np.zeros((80, 96, 3), dtype=np.float32)
+        for k in range(3):
+            r.render_shard(scene, cfg, shard_index=k, shard_count=3, strip_rows=16, film=film, wait=False)
+        r.wait(scene)
+        assert np.array_equal(film.view(np.uint32), want[3].view(np.uint32))
+    lib = spt.hip_lib()
+    p = spt.PathTracer(max_depth=2, spp=1).params(16, 16, 0, 1, 16, 0, spt.RENDER_ASYNC)
+    out = np.zeros((16, 16, 3), dtype=np.float32)
+    st = spt.RenderStats()
+    cam = sc.get_camera(None)
+    assert lib.spt_render(sc.device_scene(0)._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(st)) == 1
+    assert b"ASYNC" in lib.spt_last_error()
