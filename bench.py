@@ -168,7 +168,9 @@ def main():
 
     spt = load_pkg()
     scene = spt.load_scene(args.scene)
-    strip_rows = 16
+    # interleave granularity of the row strips: finer strips even out the ranks' shares of the object (8 ranks, slowest / mean
+    # rank on one GPU: 0.634 / 0.550 ms with 16-row strips, 0.602 / 0.571 ms with 4-row strips; tools/strip_rows_test.py)
+    strip_rows = 16 if world < 8 else 4
     scene.device_scene(local_rank)   # scene upload: outside every timed region (inputs resident in HBM)
 
     def barrier():
@@ -350,9 +352,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "scenes_amd/cfg2_cube.json (= reference scenes/test_scene_01.json) + pt.json, "
-                                   "%dx%d @ %d spp, max_depth %d, recurrence sampler; the SAME image for every N (%d row strips of 16 "
+                                   "%dx%d @ %d spp, max_depth %d, recurrence sampler; the SAME image for every N (%d row strips of %d "
                                    "dealt round-robin to %d rank(s))" % (args.width, args.height, renderer.spp, renderer.max_depth,
-                                                                      (args.height + strip_rows - 1) // strip_rows, world),
+                                                                      (args.height + strip_rows - 1) // strip_rows, strip_rows, world),
                        "width": args.width, "height": args.height, "spp": renderer.spp, "seed": 1,
                        "samples_per_step": samples_per_step,
                        "sharding": "interleaved %d-row strips over %d rank(s); each rank writes its rows into one shared-memory film "

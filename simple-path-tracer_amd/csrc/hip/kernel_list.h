@@ -49,6 +49,7 @@
 #define SPT_KERNELS_SHADE0(X)                                        \
     X((k_shade<0, true, true, true, true>), SPT_ARGS_BOUNCE)         \
     X((k_shade<0, false, true, true, true>), SPT_ARGS_BOUNCE)        \
+    X((k_shade<0, false, true, true, true, true>), SPT_ARGS_BOUNCE)  \
     X((k_shade<0, true, false, true, true>), SPT_ARGS_BOUNCE)        \
     X((k_shade<0, false, false, true, true>), SPT_ARGS_BOUNCE)       \
     X((k_shade<0, true, false, false, false>), SPT_ARGS_BOUNCE)      \

@@ -359,8 +359,15 @@ SPT_DEV void rad_store(const RenderCtx& rc, uint32_t slot, f3 c) {
 // kGeoLds (kFeat 3 only): the BSSRDF probe walks the LDS-staged traversal geometry.  It has to follow the SCENE
 // (lds_geo), not kTab: a scene whose geometry fits LDS but whose shading tables do not runs the un-tabbed kernel, and
 // its global blob holds the LDS node format, which only the kLds walker reads.
-template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab>
+//
+// kLoop (fused kernels of bounce >= 1 only): a vertex produced by the extension trace inside this kernel is shaded by the
+// same lane in the next turn of an inner loop instead of travelling through the queue to the next launch, down to the
+// last bounce.  The host picks it when the previous pass showed that few paths are left after bounce 0 (cfg2: a cube in
+// the void): the 2 x 6 launches of bounces 2 .. 7, each ~9.5 us of dispatch for nothing, are never made.  Same
+// arithmetic per path, the same additions to its radiance slot in the same order; the queue counters still count.
+template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab, bool kLoop = false>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+    static_assert(!kLoop || (kFused && !kFirst), "the in-kernel bounce loop exists for the fused kernels of bounce >= 1");
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3;
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
@@ -401,7 +408,14 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             if (kFirst || kFused) pre_b = rc.qa.d_pdf[k];
             if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
         }
-        bool want_shadow = false, want_ext = false;
+        // kLoop: a lane's vertex of the next bounce, handed from the end of one turn to the start of the next
+        bool carried = false, lane_on = active;
+        DRay c_ray;
+        c_ray.o = mk3(0, 0, 0); c_ray.d = mk3(0, 0, 0); c_ray.t_min = 0.0f;
+        float c_pdf = 0.0f;
+        DHit c_h;
+        c_h.t = 0.0f; c_h.inst = -1; c_h.prim = -1; c_h.v = 0.0f; c_h.w = 0.0f;
+        uint32_t b_cur = bounce;
         // Bounce 0 owns the first contributions of a camera sample: they are summed here, starting from the 0 the slot
         // would hold, in the order the read-modify-writes would have been made, and the slot is WRITTEN once at the end of
         // the iteration (k_primary does not zero it).  Later bounces and k_shadow / k_extend add to the slot as before.
@@ -411,18 +425,26 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             else rad_add(rc, sl, c);
         };
         DRay shadow_ray, next_ray;
-        float shadow_tmax = 0.0f, next_pdf = 0.0f;
-        f3 contrib = mk3(0, 0, 0), thr = gray(1.0f), lsi = mk3(0, 0, 0);
+        f3 thr = gray(1.0f), lsi = mk3(0, 0, 0);
         uint32_t slot = 0u, depth = 0u;
         int32_t medium = -1;
         DRng rng;
         rng.s.state = 0ull;
-        if (active) {
+        bool want_shadow = false, want_ext = false;
+        float shadow_tmax = 0.0f, next_pdf = 0.0f;
+        f3 contrib = mk3(0, 0, 0);
+        for (;;) {   // one turn, or (kLoop) one turn per bounce
+        want_shadow = false; want_ext = false;
+        contrib = mk3(0, 0, 0);
+        if (lane_on) {
             float4 hv = kPrefetch ? cur_hv : rc.hits.t_v_w_prim[idx];
             DRay ray;
             float last_pdf;
             f3 aux_xd = mk3(0, 0, 0), aux_yd = mk3(0, 0, 0);
-            if (kFirst) {
+            if (kLoop && carried) {   // (thr, slot, lsi, depth, medium, rng are where the previous turn left them)
+                ray = c_ray;
+                last_pdf = c_pdf;
+            } else if (kFirst) {
                 // rebuild the constants of a camera path from the slot (see k_primary)
                 const float4 b = kPrefetch ? cur_b : rc.qa.d_pdf[idx];
                 slot = __float_as_uint(b.w);
@@ -473,6 +495,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             DHit h;
             h.t = hv.x; h.v = hv.y; h.w = hv.z; h.prim = __float_as_int(hv.w);
             h.inst = (int32_t)cur_is.x;
+            if (kLoop && carried) h = c_h;
             const bool does_hit = h.inst >= 0;
             bool alive = true;       // false: path ended without the RR / depth tail (`break`)
             bool scattered = false;  // a new ray was produced (tail applies)
@@ -666,13 +689,13 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
         }
         if (kFused) {
             // the two queue counters still count the segments (spt_render_stats); the slots are not used
-            const PendingPush ps = wave_push_issue(want_shadow, shadow_count);
-            const PendingPush pe = wave_push_issue(want_ext, ext_count);
+            const PendingPush ps = wave_push_issue(want_shadow, kLoop ? q_count(rc.counts, b_cur, Q_SHADOW, shard) : shadow_count);
+            const PendingPush pe = wave_push_issue(want_ext, kLoop ? q_count(rc.counts, b_cur, Q_EXT, shard) : ext_count);
             if (want_shadow && !trace_any<true>(sc, shadow_ray, shadow_tmax)) slot_add(slot, contrib);   // k_shadow
             bool keep = false;                                                                               // k_extend
             DHit nh;
             nh.inst = -1; nh.t = SPT_F32_MAX; nh.prim = -1; nh.v = 0.0f; nh.w = 0.0f;
-            if (want_ext && bounce + 1u < rc.max_depth) {   // the host launches no k_extend after the last bounce either
+            if (want_ext && b_cur + 1u < rc.max_depth) {   // the host launches no k_extend after the last bounce either
                 nh = trace_closest<true>(sc, next_ray, SPT_F32_MAX);
                 if (nh.inst >= 0 || medium >= 0) {
                     keep = true;
@@ -687,14 +710,24 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t
             if (kFirst && active) rad_store(rc, slot, first_acc);
             (void)wave_push_finish(ps);
             (void)wave_push_finish(pe);
-            const uint32_t ns = qbase + wave_push(keep, q_count(rc.counts, bounce + 1, Q_HIT, shard));
+            const uint32_t ns = qbase + wave_push(keep, q_count(rc.counts, b_cur + 1, Q_HIT, shard));
+            if (kLoop) {
+                carried = true;
+                lane_on = keep;
+                if (keep) { c_ray = next_ray; c_pdf = next_pdf; c_h = nh; }
+                if (__ballot(lane_on) == 0ull) break;   // wave-uniform: every lane's path has ended
+                b_cur += 1u;
+                continue;
+            }
             if (keep) {
                 store_path(rc.qb, ns, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
                 rc.hits_next.t_v_w_prim[ns] = make_float4(nh.t, nh.v, nh.w, __int_as_float(nh.prim));
                 rc.hits_next.inst_src[ns] = make_uint2((uint32_t)nh.inst, ns);
             }
-            continue;
         }
+        break;
+        }   // turns
+        if (kFused) continue;
         if (kFirst && active) rad_store(rc, slot, first_acc);   // before k_shadow / k_extend of this bounce add to it
         // both reservations in flight together: one atomic round trip per iteration instead of two
         const PendingPush ps = wave_push_issue(want_shadow, shadow_count);

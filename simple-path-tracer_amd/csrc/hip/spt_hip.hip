@@ -495,6 +495,9 @@ struct spt_scene {
     hipStream_t stream_copy = nullptr;        // SPT_RENDER_ASYNC: the film's D2H copy, next to the following render's kernels
     hipEvent_t ev_out_ready = nullptr, ev_copy_done = nullptr;
     bool copy_pending = false;                // an asynchronous copy-out of `out` may still be in flight
+    // what the last pass with a counter readback saw at bounce 1 (path vertices in all shards); ~0: never seen.  A hint
+    // only: it picks between two kernels that compute the same film (k_shade's kLoop)
+    uint64_t tail_vertices = ~0ull;
     DScene d{};
     DeviceBuffer tri_pos, tri_attr, instances, meshes, spheres, bezier, surfaces, materials, mediums, lights;
     DeviceBuffer light_props, light_u, light_k, env_px, env_uk, geo;
@@ -708,6 +711,9 @@ constexpr uint32_t kBlock = 256;
 // no better (cfg2 60.5 / 61.8 / 62.1 Gsamples/s for 1 / 2 / 3 resident rounds vs 62.4 with this fixed grid, cfg4 4.49
 // vs 4.61): items cost very different amounts, so more, smaller work shares balance better than an exact fit.
 constexpr uint32_t kPersistentBlocks = 2048;
+// bounce-1 vertices per pass below which the fused pipeline stops launching per bounce (a lane that loops over its path
+// wastes the lanes whose paths ended; with this few vertices that costs microseconds, the launches it saves ~0.1 ms)
+constexpr uint64_t kTailLoopBelow = 4ull << 20;
 
 }  // namespace
 
@@ -1497,9 +1503,14 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         // (qa, hits) for even b and in (qb, hits_next) for odd b
                         RenderCtx rb = rc;
                         if (b & 1u) { std::swap(rb.qa, rb.qb); std::swap(rb.hits, rb.hits_next); }
+                        // few vertices left after bounce 0 (seen by the previous pass with a counter readback): bounce 1 and
+                        // everything after it in ONE launch, each lane following its path to the end (k_shade's kLoop)
+                        const bool tail_loop = b == 1 && sc->tail_vertices <= kTailLoopBelow && std::getenv("SPT_NO_TAIL_LOOP") == nullptr;
                         if (b == 0) hipLaunchKernelGGL((k_shade<0, true, true, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
+                        else if (tail_loop) hipLaunchKernelGGL((k_shade<0, false, true, true, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
                         else hipLaunchKernelGGL((k_shade<0, false, true, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, rb, b);
                         end();
+                        if (tail_loop) break;
                         continue;
                     }
                     // un-fused: the shade stage of bounce b reads the path records its predecessor wrote (ru.qa) through the
@@ -1577,6 +1588,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * Q_KINDS + q) * kShards + s) * 32];
                         return t;
                     };
+                    if (p.max_depth > 1) sc->tail_vertices = qsum(1, Q_HIT);
                     primary_hits += qsum(0, Q_HIT);
                     shadow_first += qsum(0, Q_SHADOW);
                     if (p.max_depth > 1) vertices_second += qsum(1, Q_HIT);

@@ -164,6 +164,7 @@ SWITCHES = [
     {"SPT_NO_LDS_GEO": "1", "SPT_STREAM_MASK": "7", "SPT_STREAM_IFIF": "0", "SPT_STREAM_ROUNDS": "2", "SPT_STREAM_REFILL": "64"},   # while-while
     {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3"},                               # kind-sorted traversal (wst.h) for shadow and extension rays
     {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3", "SPT_REFERENCE_BVH": "1"},
+    {"SPT_NO_TAIL_LOOP": "1"},                                                  # fused scenes: one launch per bounce even when few paths are left
     {"SPT_NO_PIXEL_CULL": "1"},
     {"SPT_NO_OVERLAP": "1"},
     {"SPT_PRIMARY_CHUNKS": "1"},

@@ -126,6 +126,32 @@ def test_render_all_branches_match_oracle(spt, scene_name, camera, sampler):
     assert mism == 0, "radiance not bit-exact: %d words differ, L1 %.3g" % (mism, l1)
 
 
+def test_tail_loop_kernel_gives_the_same_film_and_counters(spt, monkeypatch):
+    """Fused scenes: once a pass has shown that few vertices are left after bounce 0, bounce 1 and everything behind it run
+    in ONE launch whose lanes follow their paths to the end (k_shade's kLoop).  Same film, same segment counters."""
+    monkeypatch.delenv("SPT_NO_TAIL_LOOP", raising=False)
+    for name in ("cfg2_cube.json", "cfg1_sphere.json"):
+        sc = _scene(spt, name)
+        r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RANDOM, spp=24, seed=9)
+        cfg = spt.OutputConfig(192, 160)
+        ref, _ = _util.oracle_render(sc, r, 192, 160, flags=_util.device_oracle_flags())
+        first = r.render_shard(sc, cfg).copy()                 # no hint yet: one launch per bounce
+        st1 = r.last_stats
+        one = (st1.segments_closest, st1.segments_shadow, st1.path_vertices, st1.vertices_second)
+        second = r.render_shard(sc, cfg, profile=True).copy()  # the hint of the first render: the looping kernel
+        st2 = r.last_stats
+        assert st2.kernel_launches[1] == 1, "bounces >= 1 were not served by one launch"      # SPT_K_SHADE
+        assert (st2.segments_closest, st2.segments_shadow, st2.path_vertices, st2.vertices_second) == one
+        third = r.render_shard(sc, cfg, samples_per_pass=7)    # several passes
+        for film in (first, second, third):
+            assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+        monkeypatch.setenv("SPT_NO_TAIL_LOOP", "1")
+        r.render_shard(sc, cfg, profile=True)
+        assert r.last_stats.kernel_launches[1] == 7
+        monkeypatch.delenv("SPT_NO_TAIL_LOOP")
+        sc.close()
+
+
 def test_shard_layout_does_not_change_pixels(spt):
     sc = _scene(spt, "cfg2_cube.json")
     r = spt.PathTracer(max_depth=8, spp=8, seed=3)
