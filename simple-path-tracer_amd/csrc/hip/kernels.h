@@ -360,13 +360,17 @@ SPT_DEV void rad_store(const RenderCtx& rc, uint32_t slot, f3 c) {
 // (lds_geo), not kTab: a scene whose geometry fits LDS but whose shading tables do not runs the un-tabbed kernel, and
 // its global blob holds the LDS node format, which only the kLds walker reads.
 //
+#ifndef SPT_SHADE0_WAVES
+#define SPT_SHADE0_WAVES 0   // waves / SIMD the fused bounce-0 kernel is compiled for; 0 = no bound (146 VGPRs, 3 waves).
+                             // MEASURED with 4 (128 VGPRs, 20 spilled): cfg2 shade_first 1.44 -> 1.96 ms per step; not kept
+#endif
 // kLoop (fused kernels of bounce >= 1 only): a vertex produced by the extension trace inside this kernel is shaded by the
 // same lane in the next turn of an inner loop instead of travelling through the queue to the next launch, down to the
 // last bounce.  The host picks it when the previous pass showed that few paths are left after bounce 0 (cfg2: a cube in
 // the void): the 2 x 6 launches of bounces 2 .. 7, each ~9.5 us of dispatch for nothing, are never made.  Same
 // arithmetic per path, the same additions to its radiance slot in the same order; the queue counters still count.
 template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab, bool kLoop = false>
-__global__ void __launch_bounds__(256) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : 1) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     static_assert(!kLoop || (kFused && !kFirst), "the in-kernel bounce loop exists for the fused kernels of bounce >= 1");
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3;
     const uint32_t shard = blockIdx.x % kShards;
