@@ -193,3 +193,35 @@ def test_scene_loader_turns_patches_into_instances(tmp_path):
         with pytest.raises(spt.SptError) as e:
             spt.load_scene(str(tmp_path / "b.json"))
         assert e.value.status == status and word in str(e.value)
+
+
+REF_MODELS = "/root/reference/scenes/models"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="the reference's model files are only present in the build container")
+@pytest.mark.parametrize("model,fas", [("cube.ply", 3), ("letter-p.ply", 2), ("letter-p.ply", 3)])
+def test_reference_models_subdivide_onto_their_limit_surface(model, fas):
+    """The control meshes the reference's scenes 19 / 20 use (scenes/common_primitives.json: `letter-p.ply`, `cube_crease.ply`;
+    `cube.ply` next to them), read in place as data: the patches pass through the limit surface the independent numpy
+    subdivision finds.  (Blender's `vertex_indices` spelling of the face list is accepted like `vertex_index`.)"""
+    v, faces = read_ply(os.path.join(REF_MODELS, model))
+    size = np.abs(v).max()
+    for _ in range(4 if model.startswith("letter") else 5):
+        v, faces = subdivide(v, faces)
+    cloud = limit_points(v, faces)
+    patches = spt.catmull_clark_patches(os.path.join(REF_MODELS, model), fas).astype(np.float64)
+    assert len(patches) > 100 and np.isfinite(patches).all()
+    corners = patches[:, [0, 0, 3, 3], [0, 3, 0, 3], :].reshape(-1, 3)
+    assert nearest(corners, cloud).max() < 3e-5 * max(size, 1.0)
+    mids = np.array([bezier_eval(p, a, b) for p in patches for a, b in ((0.5, 0.5), (0.5, 0.0), (0.0, 0.5))])
+    assert nearest(mids, cloud).max() < 0.03 * size
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="the reference's model files are only present in the build container")
+def test_reference_crease_cube():
+    """scenes/models/cube_crease.ply: eight edges (bottom ring + verticals) of sharpness 2 in the `element edge` block."""
+    crease = spt.catmull_clark_patches(os.path.join(REF_MODELS, "cube_crease.ply"), 4)
+    smooth = spt.catmull_clark_patches(os.path.join(REF_MODELS, "cube.ply"), 4)
+    assert len(crease) == len(smooth) == 240 and np.isfinite(crease).all()
+    # creases keep the surface out at the sharp edges: it reaches farther than the smooth blob, but nowhere past the cage
+    assert np.abs(smooth).max() < 0.85 and 0.9 < np.abs(crease).max() <= 1.0 + 1e-6
