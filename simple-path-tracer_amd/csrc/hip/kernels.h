@@ -29,6 +29,22 @@
 // pixels are summed in sample order, so the film is bit-reproducible and identical
 // for any shard layout / GPU count.
 #pragma once
+// waves / SIMD the latency-bound large-scene kernels are compiled for (see DESIGN.md "Registers and occupancy")
+#ifndef SPT_W_EXT
+#define SPT_W_EXT 4   // cfg5 extension rays (streaming walker): 88.9 ms at 3 waves (146 VGPRs), 78.0 at 4 (128, 14 spilled), 129 at 5 (96, 95 spilled)
+#endif
+#ifndef SPT_W_SHD_L
+#define SPT_W_SHD_L 6   // cfg4 shadow (LDS-resident): 17.2 ms unbounded (84 VGPRs, 5 waves), 17.1 at 6 (80), 21.3 at 8 (64, 30 spilled)
+#endif
+#ifndef SPT_W_EXT_L
+#define SPT_W_EXT_L 5   // cfg4 extension rays: 27.9 ms unbounded (100 VGPRs, 4 waves), 26.8 at 5 (96, none spilled), 31.0 at 6 (80, 18 spilled)
+#endif
+#ifndef SPT_W_SHD
+#define SPT_W_SHD 6   // cfg5 shadow: 9.9 ms at 4 waves (98 VGPRs), 9.1 at 5, 8.75 at 6 (80 VGPRs, 5 spilled)
+#endif
+#ifndef SPT_W_PRI
+#define SPT_W_PRI 5   // cfg5 primary: 8.6 ms at 4 waves (111 VGPRs), 8.3 at 5 (96, 9 spilled), 9.6 at 6 (80, 28 spilled)
+#endif
 #include "shading.h"
 #include "stream.h"
 
@@ -219,7 +235,7 @@ SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % 
 // which adds the slots in sample order: the same additions in the same order as the register sum of the
 // un-chunked kernel (a miss adds exactly +0 or its environment term), so the film is bit-identical.
 template <bool kLds, bool kChunked = false, bool kCount = false>
-__global__ void __launch_bounds__(256) k_primary(DScene sc, RenderCtx rc) {
+__global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI : 1) k_primary(DScene sc, RenderCtx rc) {
     stage_geometry<kLds>(sc);
     LaneVisits vc{0u, 0u, 0u};
     const uint32_t tile = kChunked ? blockIdx.x % rc.n_tiles : blockIdx.x, chunk = kChunked ? blockIdx.x / rc.n_tiles : 0u;
@@ -749,7 +765,7 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
 
 // ---------------------------------------------------------------------------- shadow
 template <bool kLds, bool kCount = false>
-__global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_SHD_L : 1) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
     if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
@@ -769,7 +785,7 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, RenderCtx rc, uint32_
 
 // ---------------------------------------------------------------------------- extend
 template <bool kLds, bool kCount = false>
-__global__ void __launch_bounds__(256) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L : 1) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
     if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
@@ -843,7 +859,7 @@ SPT_DEV uint32_t wave_pull(bool want, uint32_t* cursor) {
 }
 
 template <bool kCount>
-__global__ void __launch_bounds__(256, 2) k_shadow_dyn(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_SHD) k_shadow_dyn(DScene sc, RenderCtx rc, uint32_t bounce) {
     stage_geometry<false>(sc);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
@@ -988,7 +1004,7 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
 }
 
 template <bool kCount>
-__global__ void __launch_bounds__(256, 2) k_extend_stream(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend_stream(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
     uint32_t* cursor = q_count(rc.counts, bounce, Q_EXT_CURSOR, shard);
