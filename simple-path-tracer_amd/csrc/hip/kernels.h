@@ -31,7 +31,7 @@
 #pragma once
 // waves / SIMD the latency-bound large-scene kernels are compiled for (see DESIGN.md "Registers and occupancy")
 #ifndef SPT_W_EXT
-#define SPT_W_EXT 4   // cfg5 extension rays (streaming walker): 88.9 ms at 3 waves (146 VGPRs), 78.0 at 4 (128, 14 spilled), 129 at 5 (96, 95 spilled)
+#define SPT_W_EXT 4   // cfg5 extension rays (streaming walker): 88.9 ms at 3 waves (146 VGPRs), 78.0 at 4 (128, 14 spilled) and 69.6 once a leaf loads its triangles two at a time (3 spilled); 5 waves (96, 67 - 95 spilled): 104 - 129 ms
 #endif
 #ifndef SPT_W_SHD_L
 #define SPT_W_SHD_L 6   // cfg4 shadow (LDS-resident): 17.2 ms unbounded (84 VGPRs, 5 waves), 17.1 at 6 (80), 21.3 at 8 (64, 30 spilled)

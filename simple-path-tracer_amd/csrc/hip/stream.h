@@ -176,30 +176,35 @@ struct SWalker {
         else pop_next(spill);
     }
 
-    // a BLAS leaf: every triangle of the leaf is requested before the first one is tested
+    // a BLAS leaf: its triangles are requested two at a time (a leaf of the device-built trees holds 1 - 4, most hold
+    // 1 or 2; four at once were 48 registers of loads in flight, which cost the kernel its fourth wave per SIMD)
     SPT_DEV void tri_leaf_step(const DScene& sc, const uint2* spill) {
         const uint32_t first = leaf_first(cur), count = leaf_count(cur);
         const float4* tp = sc.geo + (sc.o_tri + 3u * first);
-        float4 ta[4], tb[4], tc[4];
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i)
-            if (i < count) { ta[i] = tp[3u * i]; tb[i] = tp[3u * i + 1u]; tc[i] = tp[3u * i + 2u]; }
         DRay orr;
         orr.o = ro; orr.d = rd; orr.t_min = t_min;
 #pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i) {
-            if (i < count && !done) {
-                float t, v, w;
-                count_tri<kCount>(&vc);
-                const bool ok = tri_test_edges(ta[i], tb[i], tc[i], orr, &t, &v, &w);
-                const int32_t id = __float_as_int(ta[i].w);
-                if (kClosest) {
-                    if (ok && t > t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, id, h)))) {  // triangle.rs:187
-                        h.t = t; h.inst = (int32_t)inst; h.prim = id; h.v = v; h.w = w;
+        for (uint32_t base = 0; base < 4u; base += 2u) {
+            if (base >= count || done) break;
+            float4 ta[2], tb[2], tc[2];
+#pragma unroll
+            for (uint32_t i = 0; i < 2u; ++i)
+                if (base + i < count) { ta[i] = tp[3u * (base + i)]; tb[i] = tp[3u * (base + i) + 1u]; tc[i] = tp[3u * (base + i) + 2u]; }
+#pragma unroll
+            for (uint32_t i = 0; i < 2u; ++i) {
+                if (base + i < count && !done) {
+                    float t, v, w;
+                    count_tri<kCount>(&vc);
+                    const bool ok = tri_test_edges(ta[i], tb[i], tc[i], orr, &t, &v, &w);
+                    const int32_t id = __float_as_int(ta[i].w);
+                    if (kClosest) {
+                        if (ok && t > t_min && (t < h.t || (t == h.t && h.inst >= 0 && key_less((int32_t)inst, id, h)))) {  // triangle.rs:187
+                            h.t = t; h.inst = (int32_t)inst; h.prim = id; h.v = v; h.w = w;
+                        }
+                    } else if (ok && t > t_min && t < h.t) {
+                        h.inst = (int32_t)inst;
+                        done = true;
                     }
-                } else if (ok && t > t_min && t < h.t) {
-                    h.inst = (int32_t)inst;
-                    done = true;
                 }
             }
         }
