@@ -643,10 +643,19 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                             thr = thr * crcp(ssio.sp, ssio.pdf_pi);
                         }
                     } else {
+#ifdef SPT_EXP_CHEAP_SAMPLE
+                        samp.wi = reflect_z(wo); samp.f = gray(1.0f); samp.pdf = 1.0f; samp.transmit = false;
+                        (void)rng.next();
+#else
                         samp = mat_sample(mt, wo, rng);
+#endif
                     }
                     lsi = po;
+#ifdef SPT_EXP_NO_LIGHT   /* measurement-only builds (tools/shade_attribution.sh): the film is WRONG */
+                    if (false) {
+#else
                     if (!mat_is_delta(mt)) {
+#endif
                         DLightSample ls;
                         if (sample_light<kSimple, kTex, kTab>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
