@@ -61,4 +61,7 @@ void decode_png_rgba8(const std::vector<uint8_t>& bytes, const std::string& labe
 void decode_jpeg_rgba8(const std::vector<uint8_t>& bytes, const std::string& label, uint32_t* width, uint32_t* height, std::vector<uint32_t>* texels);
 void encode_jpeg_rgb8(const uint8_t* rgb, uint32_t w, uint32_t h, int quality, std::vector<uint8_t>* out);
 
+// exr_piz.cpp: one PIZ-compressed block of an OpenEXR scanline file -> the bytes of the uncompressed block
+void exr_piz_decode(const uint8_t* src, size_t size, const std::vector<int>& words_per_pixel, int64_t width, int64_t lines, uint8_t* raw, size_t raw_bytes);
+
 }  // namespace spt_host

@@ -3,7 +3,7 @@
 // reader/writer for `environment {type: "exr"}` (get_exr_image, reference
 // src/core/loader.rs:374-390 reads the first RGBA layer as f32).
 // Supported EXR subset: single-part scanline files, channels R,G,B (A ignored) of
-// type HALF or FLOAT, compression NONE / RLE / ZIPS / ZIP / PXR24, any line order.
+// type HALF or FLOAT, compression NONE / RLE / ZIPS / ZIP / PIZ (exr_piz.cpp) / PXR24, any line order.
 #include <zlib.h>
 
 #include <cmath>
@@ -255,11 +255,11 @@ spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height
             }
             r.p = end;
         }
-        if (compression != 0 && compression != 1 && compression != 2 && compression != 3 && compression != 5)
-            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: only NONE / RLE / ZIPS / ZIP / PXR24 compression is supported (not PIZ, B44, DWA)");
+        if (compression < 0 || compression > 5)
+            throw HostError(SPT_HOST_ERR_UNSUPPORTED, "exr: only NONE / RLE / ZIPS / ZIP / PIZ / PXR24 compression is supported (not B44, DWA)");
         int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
         if (w <= 0 || h <= 0 || w > 65536 || h > 65536) throw HostError(SPT_HOST_ERR_PARSE, "exr: bad dataWindow");
-        int lines_per_block = (compression == 3 || compression == 5) ? 16 : 1;
+        int lines_per_block = (compression == 3 || compression == 5) ? 16 : (compression == 4 ? 32 : 1);
         int64_t n_blocks = (h + lines_per_block - 1) / lines_per_block;
         size_t row_bytes = 0;
         std::vector<size_t> chan_off(chans.size());
@@ -293,6 +293,10 @@ spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height
                 if (compression == 0 || (size_t)size == want) {
                     if ((size_t)size != want) throw HostError(SPT_HOST_ERR_PARSE, "exr: chunk size mismatch");
                     std::memcpy(raw.data(), &data[r.p], want);
+                } else if (compression == 4) {
+                    std::vector<int> wpp;
+                    for (const Chan& c : chans) wpp.push_back(c.type == 1 ? 1 : 2);
+                    spt_host::exr_piz_decode(&data[r.p], (size_t)size, wpp, w, lines, raw.data(), want);
                 } else if (compression == 5) {
                     // PXR24 (ImfPxr24Compressor): zlib over byte planes of per-row, per-channel running differences;
                     // FLOAT samples keep their top 24 bits

@@ -62,6 +62,172 @@ def _pxr24(rows, types):
     return zlib.compress(bytes(out))
 
 
+# ---- PIZ (ImfPizCompressor / ImfHuf / ImfWav, written from the format description like the decoder it tests) ----------
+def _wenc14(a, b):
+    a = a - 65536 if a >= 32768 else a
+    b = b - 65536 if b >= 32768 else b
+    return ((a + b) >> 1) & 0xffff, (a - b) & 0xffff
+
+
+def _wenc16(a, b):
+    ao = (a + 0x8000) & 0xffff
+    m = (ao + b) >> 1
+    d = ao - b
+    if d < 0:
+        m = (m + 0x8000) & 0xffff
+    return m, d & 0xffff
+
+
+def _wav2_encode(buf, start, nx, ox, ny, oy, mx):
+    enc = _wenc14 if mx < (1 << 14) else _wenc16
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        py, ey = 0, oy * (ny - p2)
+        while py <= ey:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                i = start + px
+                i00, i01 = enc(buf[i], buf[i + ox1])
+                i10, i11 = enc(buf[i + oy1], buf[i + oy1 + ox1])
+                buf[i], buf[i + oy1] = enc(i00, i10)
+                buf[i + ox1], buf[i + oy1 + ox1] = enc(i01, i11)
+                px += ox2
+            if nx & p:
+                i = start + px
+                buf[i], buf[i + oy1] = enc(buf[i], buf[i + oy1])
+            py += oy2
+        if ny & p:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                i = start + px
+                buf[i], buf[i + ox1] = enc(buf[i], buf[i + ox1])
+                px += ox2
+        p, p2 = p2, p2 << 1
+
+
+def _huf_compress(data, use_runs=True):
+    import heapq
+    freq = {}
+    for v in data:
+        freq[v] = freq.get(v, 0) + 1
+    im, i_max = min(freq), max(freq) + 1
+    freq[i_max] = 1                                        # the run-length escape
+    syms = sorted(freq)
+    heap = [(freq[sym], k) for k, sym in enumerate(syms)]
+    heapq.heapify(heap)
+    parent = list(range(len(syms)))                        # leaves 0 .. n-1, inner nodes appended
+    while len(heap) > 1:
+        fa, a = heapq.heappop(heap)
+        fb, b = heapq.heappop(heap)
+        parent.append(len(parent))
+        parent[a] = parent[b] = len(parent) - 1
+        heapq.heappush(heap, (fa + fb, len(parent) - 1))
+    depth = [0] * len(parent)
+    for node in range(len(parent) - 2, -1, -1):            # a parent always has the larger index
+        depth[node] = depth[parent[node]] + 1
+    length = {sym: depth[k] for k, sym in enumerate(syms)}
+    assert max(length.values()) <= 58
+    # canonical codes exactly as the decoder assigns them
+    n = [0] * 59
+    for l in length.values():
+        n[l] += 1
+    n[0] += 65537 - len(length)
+    c = 0
+    for i in range(58, 0, -1):
+        nc = (c + n[i]) >> 1
+        n[i] = c
+        c = nc
+    code = {}
+    for sym in range(im, i_max + 1):
+        l = length.get(sym, 0)
+        if l:
+            code[sym] = n[l]
+            n[l] += 1
+    bits = []                                              # (value, nbits)
+    sym = im
+    while sym <= i_max:
+        l = length.get(sym, 0)
+        if l == 0:
+            run = 1
+            while sym + run <= i_max and length.get(sym + run, 0) == 0 and run < 261:
+                run += 1
+            if run >= 6:
+                bits += [(63, 6), (run - 6, 8)]
+                sym += run
+                continue
+            if run >= 2:
+                bits.append((59 + run - 2, 6))
+                sym += run
+                continue
+        bits.append((l, 6))
+        sym += 1
+    table = _pack_bits(bits)
+    out = []
+
+    def send(sym, run):
+        ls, lr = length[sym], length[i_max]
+        if use_runs and ls + lr + 8 < ls * run:
+            out.extend([(code[sym], ls), (code[i_max], lr), (run, 8)])
+        else:
+            out.extend([(code[sym], ls)] * (run + 1))
+    cur, run = data[0], 0
+    for v in data[1:]:
+        if v == cur and run < 255:
+            run += 1
+        else:
+            send(cur, run)
+            cur, run = v, 0
+    send(cur, run)
+    n_bits = sum(b for _, b in out)
+    body = _pack_bits(out)
+    return struct.pack("<IIIII", im, i_max, len(table), n_bits, 0) + table + body
+
+
+def _pack_bits(items):
+    acc, nb, out = 0, 0, bytearray()
+    for v, b in items:
+        acc = (acc << b) | v
+        nb += b
+        while nb >= 8:
+            nb -= 8
+            out.append((acc >> nb) & 255)
+        acc &= (1 << nb) - 1
+    if nb:
+        out.append((acc << (8 - nb)) & 255)
+    return bytes(out)
+
+
+def _piz(rows, types, use_runs=True):
+    """rows: per scanline, per channel (file order) a numpy array of w samples -> one PIZ block"""
+    ny, nx = len(rows), len(rows[0][0])
+    buf, starts = [], []
+    for c, ty in enumerate(types):
+        starts.append(len(buf))
+        for line in rows:
+            buf += line[c].view(np.uint16).tolist()       # f16: one word per sample; f32: low word, high word
+    used = sorted(set(buf) | {0})
+    nonzero = [v for v in used if v]
+    bitmap = bytearray(8192)
+    for v in nonzero:
+        bitmap[v >> 3] |= 1 << (v & 7)
+    fwd = {v: k for k, v in enumerate(used)}
+    buf = [fwd[v] for v in buf]
+    mx = len(used) - 1
+    for c, ty in enumerate(types):
+        wpp = 1 if ty == 1 else 2
+        for j in range(wpp):
+            _wav2_encode(buf, starts[c] + j, nx, wpp, ny, nx * wpp, mx)
+    if nonzero:
+        lo, hi = min(nonzero) >> 3, max(nonzero) >> 3
+        head = struct.pack("<HH", lo, hi) + bytes(bitmap[lo:hi + 1])
+    else:
+        head = struct.pack("<HH", 8191, 0)                 # minNonZero > maxNonZero: no bitmap bytes follow
+    huf = _huf_compress(buf, use_runs)
+    return head + struct.pack("<i", len(huf)) + huf
+
+
 def write_exr(path, img, compression, half=(False, False, False), extra_alpha=False, origin=(0, 0), decreasing_y=False):
     h, w, _ = img.shape
     names = ["B", "G", "R"] + (["A"] if extra_alpha else [])          # alphabetical, as OpenEXR stores them: A B G R
@@ -76,7 +242,7 @@ def write_exr(path, img, compression, half=(False, False, False), extra_alpha=Fa
     hdr += _attr("dataWindow", "box2i", box) + _attr("displayWindow", "box2i", box)
     hdr += _attr("lineOrder", "lineOrder", bytes([1 if decreasing_y else 0])) + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
     hdr += _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) + _attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    per = 16 if compression in (ZIP, PXR24) else 1
+    per = 16 if compression in (ZIP, PXR24) else (32 if compression == PIZ else 1)
     blocks = []
     for b0 in range(0, h, per):
         rows = []
@@ -91,9 +257,11 @@ def write_exr(path, img, compression, half=(False, False, False), extra_alpha=Fa
             data = zlib.compress(_predict_and_split(raw))
         elif compression == PXR24:
             data = _pxr24(rows, [types[n] for n in names])
+        elif compression == PIZ:
+            data = _piz(rows, [types[n] for n in names])
         else:
-            data = b"\0" * 8
-        if len(data) >= len(raw) and compression != PIZ:
+            data = b"\0" * 8                             # B44 and the rest: the reader refuses the header
+        if len(data) >= len(raw):
             data = raw                                   # OpenEXR stores a block raw when compression does not shrink it
         blocks.append((y0 + b0, data))
     order = list(reversed(blocks)) if decreasing_y else blocks         # file order; the offset table is always by increasing y
@@ -119,7 +287,7 @@ def _image(h, w, seed, smooth):
     return np.round(img.astype(np.float32) * 64) / np.float32(64)
 
 
-@pytest.mark.parametrize("compression", [NONE, RLE, ZIPS, ZIP, PXR24])
+@pytest.mark.parametrize("compression", [NONE, RLE, ZIPS, ZIP, PIZ, PXR24])
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("half", [(False, False, False), (True, True, True), (True, False, True)])
 def test_every_supported_compression_reads_back_exactly(tmp_path, compression, smooth, half):
@@ -128,6 +296,53 @@ def test_every_supported_compression_reads_back_exactly(tmp_path, compression, s
     write_exr(p, img, compression, half=half, extra_alpha=True, origin=(-5, 7), decreasing_y=(compression == ZIPS))
     got = spt.read_exr(p)
     assert got.shape == img.shape and np.array_equal(got, img)
+
+
+def test_piz_sixteen_bit_wavelet_long_codes_and_runs(tmp_path):
+    """A block with more than 2^14 distinct 16-bit words takes the modulo-2^16 wavelet and Huffman codes longer than the
+    14-bit decoding table; constant regions take the run-length escape; a block that PIZ cannot shrink is stored raw."""
+    rng = np.random.default_rng(11)
+    h, w = 40, 700                                          # 32 + 8 lines: 134 k words in the first block
+    img = rng.uniform(0, 1000, size=(h, w, 3)).astype(np.float32)
+    img[5:20, 100:400] = np.float32(2.5)                    # long runs inside the noise
+    p = str(tmp_path / "big.exr")
+    write_exr(p, img, PIZ)
+    assert np.array_equal(spt.read_exr(p), img)
+    flat = np.full((33, 64, 3), np.float32(0.75))           # one value: bitmap of one bit, every code a run
+    flat[..., 1] = 0.0                                      # and a channel that is all zero
+    write_exr(p, flat, PIZ, half=(True, False, True))
+    assert np.array_equal(spt.read_exr(p), flat)
+    zero = np.zeros((7, 9, 3), np.float32)                  # nothing but zeros: minNonZero > maxNonZero, no bitmap bytes
+    write_exr(p, zero, PIZ)
+    assert np.array_equal(spt.read_exr(p), zero)
+
+
+def test_corrupt_piz_blocks_are_reported_not_followed(tmp_path):
+    img = _image(37, 53, 4, True)
+    p = str(tmp_path / "t.exr")
+    write_exr(p, img, PIZ)
+    good = bytearray(open(p, "rb").read())
+    assert np.array_equal(spt.read_exr(p), img)
+    first = struct.unpack_from("<Q", good, good.index(b"screenWindowWidth") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1)[0]
+    size = struct.unpack_from("<i", good, first + 4)[0]
+    rng = np.random.default_rng(0)
+    outcomes = set()
+    for trial in range(300):
+        data = bytearray(good)
+        for _ in range(1 + trial % 3):
+            data[first + 8 + int(rng.integers(size))] ^= 1 << int(rng.integers(8))
+        open(p, "wb").write(bytes(data))
+        try:
+            got = spt.read_exr(p)
+            outcomes.add("read")                            # a flipped data bit can still decode, to other values
+            assert got.shape == img.shape
+        except spt.SptError as e:
+            assert e.status == 101 and "PIZ" in str(e), str(e)
+            outcomes.add("refused")
+    assert outcomes == {"read", "refused"}
+    open(p, "wb").write(bytes(good[:first + 8 + size // 2]))     # truncated inside the block
+    with pytest.raises(spt.SptError):
+        spt.read_exr(p)
 
 
 def test_pxr24_drops_the_low_byte_of_a_float_like_openexr():
@@ -145,11 +360,11 @@ def test_pxr24_drops_the_low_byte_of_a_float_like_openexr():
 
 def test_unsupported_and_corrupt_files_are_reported(tmp_path):
     img = _image(8, 8, 1, True)
-    p = str(tmp_path / "piz.exr")
-    write_exr(p, img, PIZ)
+    p = str(tmp_path / "b44.exr")
+    write_exr(p, img, 6)
     with pytest.raises(spt.SptError) as e:
         spt.read_exr(p)
-    assert "PIZ" in str(e.value)
+    assert "B44" in str(e.value) and e.value.status == 103
     p = str(tmp_path / "rle.exr")
     write_exr(p, _image(16, 64, 2, True), RLE)
     data = bytearray(open(p, "rb").read())
