@@ -52,7 +52,7 @@ spt_status spt_host_write_jpeg(const char* path, const uint8_t* rgb8, uint32_t w
 /* `image.save(path)` (src/renderer/pt.rs:292-294): the extension picks the format - png, jpg / jpeg */
 spt_status spt_host_write_image(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
-/* OpenEXR scanline I/O (RGB f32 / f16; reads NO_COMPRESSION / RLE / ZIPS / ZIP / PXR24, writes uncompressed) for
+/* OpenEXR scanline I/O (RGB f32 / f16; reads NO_COMPRESSION / RLE / ZIPS / ZIP / PIZ / PXR24, writes uncompressed) for
  * `environment {type: "exr"}` (get_exr_image, src/core/loader.rs:374-390). */
 spt_status spt_host_read_exr(const char* path, uint32_t* width, uint32_t* height, float** rgb_out);
 spt_status spt_host_write_exr(const char* path, const float* rgb, uint32_t width, uint32_t height);
