@@ -131,6 +131,17 @@ def make_scene(rng, work=None):
             m.update(int_ior=float(rng.uniform(1.3, 1.6)), albedo=colour(), ld="ld")
             roughness_fields(m)
         mats.append(m)
+    if os.environ.get("FUZZ_V3") and rng.random() < 0.45:
+        # FUZZ_V3 (round 2): position-normal-distribution materials over the scratched normal map
+        tex.append({"type": "image", "name": "scratch", "image_file": "textures/scratch_normal.png",
+                    "tiling": [float(rng.uniform(1, 6)), float(rng.uniform(1, 6))], "offset": [float(rng.uniform(0, 1)), float(rng.uniform(0, 1))]})
+        for k in range(int(rng.integers(1, 3))):
+            m = {"type": "pndf_conductor" if rng.random() < 0.6 else "pndf_plastic", "name": "glint%d" % k, "albedo": colour(),
+                 "sigma_r": float(rng.choice([0.01, 0.02, 0.05, 0.08])), "base_normal": "scratch", "h": float(rng.choice([1.0, 2.0, 3.0])),
+                 "fallback_roughness": "r%d" % int(rng.integers(0, 4))}
+            if m["type"] == "pndf_plastic":
+                m["int_ior"] = float(rng.uniform(1.3, 1.7))
+            mats.append(m)
     mats.append({"type": "pseudo", "name": "pseudo"})
     mediums = []
     for k in range(int(rng.integers(0, 3))):
@@ -148,6 +159,10 @@ def make_scene(rng, work=None):
         h = rng.uniform(-0.5, 1.2, (4, 4))
         prims.append({"type": "cubic_bezier", "name": "patch",
                       "control_points": [[[float(-1.5 + j + rng.uniform(-0.2, 0.2)), float(h[i][j]), float(1.5 - i + rng.uniform(-0.2, 0.2))] for j in range(4)] for i in range(4)]})
+    use_cc = bool(os.environ.get("FUZZ_V3")) and rng.random() < 0.3
+    if use_cc:       # Catmull-Clark surfaces: every patch an instance under the TLAS
+        model = ["cc_cube.ply", "cc_cube_crease.ply", "cc_lshape.ply", "cc_tube.ply"][int(rng.integers(0, 4))]
+        prims.append({"type": "catmull_clark", "name": "cc", "ply_file": "models/" + model, "fas_times": int(rng.integers(1, 3))})
     surfaces = []
     for k in range(int(rng.integers(0, 4))):
         s = {"name": "s%d" % k, "material": mats[int(rng.integers(0, len(mats)))]["name"]}
@@ -165,14 +180,14 @@ def make_scene(rng, work=None):
             s["normal_map"] = normal_map
         surfaces.append(s)
     inst = [{"name": "floor", "primitive": "plane", "material": mats[0]["name"], "scale": [6.0, 1.0, 6.0], "translate": [0.0, -1.2, 0.0]}]
-    names = ["ball", "off_ball", "cube", "plane", "blob"] + (["patch", "patch"] if use_patches else [])
+    names = ["ball", "off_ball", "cube", "plane", "blob"] + (["patch", "patch"] if use_patches else []) + (["cc"] if use_cc else [])
     for k in range(int(rng.integers(2, 9))):
         prim = names[int(rng.integers(0, len(names)))]
         i = {"name": "i%d" % k, "primitive": prim}
         s = None
         if surfaces and rng.random() < 0.5:
             s = surfaces[int(rng.integers(0, len(surfaces)))]
-            if prim == "patch" and "emissive" in s:
+            if prim in ("patch", "cc") and "emissive" in s:
                 s = None                                    # CubicBezier cannot be a shape light (bezier.rs:188-190)
         if s is not None:
             i["surface"] = s["name"]
@@ -247,7 +262,9 @@ def run_seed(seed, work):
     if os.environ.get("FUZZ_SWITCHES"):
         for name, values in (("SPT_NO_FUSED", ["1"]), ("SPT_NO_LDS_TABLES", ["1"]), ("SPT_NO_LDS_GEO", ["1"]), ("SPT_NO_PIXEL_CULL", ["1"]),
                              ("SPT_NO_OVERLAP", ["1"]), ("SPT_NO_DYN_SHADOW", ["1"]), ("SPT_NO_DYN_EXTEND", ["1"]), ("SPT_PRIMARY_CHUNKS", ["1", "2", "7"]),
-                             ("SPT_BOX_BAND_BYTES", ["20000", "300000"]), ("SPT_BVH_MAX_LEAF", ["1", "2", "8"]), ("SPT_DYN_BLOCKS", ["64", "512"])):
+                             ("SPT_BOX_BAND_BYTES", ["20000", "300000"]), ("SPT_BVH_MAX_LEAF", ["1", "2", "8"]), ("SPT_DYN_BLOCKS", ["64", "512"])) + \
+                            ((("SPT_NO_TAIL_LOOP", ["1"]), ("SPT_NO_STREAM", ["1"]), ("SPT_STREAM_MASK", ["0", "2", "7"]), ("SPT_STREAM_IFIF", ["0"]),
+                              ("SPT_WST_MASK", ["1", "3"]), ("SPT_BEZ_LDS", ["1"])) if os.environ.get("FUZZ_V3") else ()):
             os.environ.pop(name, None)
             if rng.random() < 0.25:
                 switches[name] = values[int(rng.integers(0, len(values)))]
@@ -257,12 +274,32 @@ def run_seed(seed, work):
     except spt.SptError as e:
         return None, "scene rejected by the loader: %s" % str(e)[:120], path
     ok, words, nan_px = True, 0, 0
+    # (hundreds of patch instances: the exhaustive oracle would test every ray against every patch; the tree-walking one
+    #  stands in - it can lose a ray that grazes the edge of an exact box, which the comparison would show)
+    flags = _util.ORACLE_DEVICE if sc.desc.n_bezier_patches > 40 else _util.device_oracle_flags()
+    v3 = bool(os.environ.get("FUZZ_V3"))
     for k in range(shard_count):
-        ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags(), shard_index=k, shard_count=shard_count, strip_rows=strip_rows)
-        got = r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=shard_count, strip_rows=strip_rows, samples_per_pass=spp_pass)
+        ref, _ = _util.oracle_render(sc, r, w, h, flags=flags, shard_index=k, shard_count=shard_count, strip_rows=strip_rows)
+        if v3 and radius == 0.5 and rng.random() < 0.5:
+            # the asynchronous path: the frame is queued twice (the second copy-out waits for nothing but the first), then awaited
+            r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=shard_count, strip_rows=strip_rows, samples_per_pass=spp_pass, reuse_output=True)
+            for _ in range(2):
+                got = r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=shard_count, strip_rows=strip_rows, samples_per_pass=spp_pass,
+                                     reuse_output=True, wait=False)
+            r.wait(sc)
+            got = got.copy()
+        else:
+            got = r.render_shard(sc, spt.OutputConfig(w, h), shard_index=k, shard_count=shard_count, strip_rows=strip_rows, samples_per_pass=spp_pass)
         nan = np.isnan(ref)
         same_nan = np.array_equal(nan, np.isnan(got))
         diff = int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum())
+        if (diff or not same_nan) and flags != _util.device_oracle_flags():
+            # the stand-in oracle walks the caller's EXACT boxes and can lose a grazing hit that the library's padded trees
+            # keep (seed 625 of the round-2 campaign: one pixel): such a film is settled by the exhaustive oracle
+            ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags(), shard_index=k, shard_count=shard_count, strip_rows=strip_rows)
+            nan = np.isnan(ref)
+            same_nan = np.array_equal(nan, np.isnan(got))
+            diff = int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum())
         ok = ok and same_nan and diff == 0
         words += diff
         nan_px += int(nan.any(axis=2).sum())
@@ -274,7 +311,10 @@ def run_seed(seed, work):
     d = np.zeros((n // 3, 3), dtype=np.float32)
     d[np.arange(n // 3), ax] = rng.choice([-1.0, 1.0], n // 3)
     rays["d"][: n // 3] = d
-    first = _util.oracle_trace_closest(sc, rays, _util.device_oracle_flags())
+    # (the rays always go against the exhaustive oracle: 6 000 rays x all patches is cheap, and axis-aligned rays are exactly
+    #  the ones that graze the exact boxes the tree-walking oracle culls with)
+    flags = _util.device_oracle_flags()
+    first = _util.oracle_trace_closest(sc, rays, flags)
     hit = first["instance"] >= 0
     restart = rays.copy()
     restart["o"][hit] = (rays["o"][hit] + rays["d"][hit] * first["t"][hit][:, None]).astype(np.float32)
@@ -285,12 +325,12 @@ def run_seed(seed, work):
     ds = sc.device_scene(0)
     ray_bad = 0
     for batch in (rays, restart):
-        ref_h = _util.oracle_trace_closest(sc, batch, _util.device_oracle_flags())
+        ref_h = _util.oracle_trace_closest(sc, batch, flags)
         got_h = ds.trace_closest(batch)
         if os.environ.get("SPT_REFERENCE_BVH"):
             continue      # coincident surfaces make a few hits visit-order dependent in that mode (tests/test_gpu_parity.py)
         ray_bad += int(ref_h.tobytes() != got_h.tobytes())
-        ray_bad += int(not np.array_equal(_util.oracle_trace_any(sc, batch, _util.device_oracle_flags()), ds.trace_any(batch)))
+        ray_bad += int(not np.array_equal(_util.oracle_trace_any(sc, batch, flags), ds.trace_any(batch)))
     ok = ok and ray_bad == 0
     kinds = sorted({m["type"] for m in scene["materials"]})
     info = ("%s  rays %s  %dx%d spp %d depth %d sampler %d radius %.1f shards %d/%d pass %d  inst %d lights %d env %s patches %d media %d  NaN px %d  words differ %d  %s" %
