@@ -263,4 +263,179 @@ SPT_DEV bool bezier_intersect_ray(const float4* cp_global, const DRay& ray, floa
     return found;
 }
 
+// The same test as a resumable walk, for the pair kernel of bezier_pairs.h ONLY (opt-in, SPT_BEZ_DEFER=1): the walkers keep
+// the function above, which the compiler turns into faster code (t_catmull.json: k_primary 27 ms against 52 ms through this
+// struct).  Identical arithmetic, call for call; tests/test_gpu_baseline_configs.py runs both against the oracle.
+// begin() projects the control points, every step()
+// is one call of the reference's bezier_clipping (depth-first, the pending right halves on `stack`), done() says when the
+// recursion has unwound; (u, v, t) of the nearest accepted candidate are left in the struct.
+// Why resumable: the clipping needs ~4 calls for most rays and 30 - 40 for a few, so a wave that runs it to the end inside
+// a traversal step waits for its slowest lane at EVERY patch; as one more phase of the stepping Walker (trace.h) a lane
+// whose test is over goes on with its traversal while the others still clip.
+// The 16-frame stack lives in the caller's scratch memory and is passed to step(): a struct that holds its own array is
+// moved to scratch as a whole (measured for the traversal walker: 2.4x slower).
+struct BzWalk {
+    BzFrame cur;
+    const float4* cp;
+    f3 ro, rd;
+    float t_min, best_t, u, v, t;
+    uint32_t sp;
+    bool found, finished;
+
+    SPT_DEV void candidate(float cu, float cv) {   // bezier.rs:121-131
+        const f3 p = bezier_point_at(cp, cu, cv);
+        const f3 diff = p - ro;
+        const f3 c = cross(diff, rd);
+        if (dot(c, c) < kClippingEps) {
+            const float tt = dot(diff, rd) / dot(rd, rd);
+            if (tt > t_min && tt < best_t) {
+                best_t = tt;
+                u = cu; v = cv; t = tt;
+                found = true;
+            }
+        }
+    }
+    SPT_DEV void begin(const float4* cp_global, const DRay& ray) {
+        cp = cp_global;
+        ro = ray.o; rd = ray.d; t_min = ray.t_min;
+        const f3 n1 = normalize(mk3(-ray.d.y, ray.d.x, 0.0f));
+        const f3 n2 = normalize(mk3(0.0f, -ray.d.z, ray.d.y));
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                const f3 diff = mk3(cp_global[4 * i + j]) - ray.o;
+                cur.p[i][j] = v2{dot(diff, n1), dot(diff, n2)};
+            }
+        cur.lu = normalize2((cur.p[3][0] - cur.p[0][0]) + (cur.p[3][3] - cur.p[0][3]));
+        cur.lv = normalize2((cur.p[0][3] - cur.p[0][0]) + (cur.p[3][3] - cur.p[3][0]));
+        cur.au0 = 1.0f; cur.au1 = 0.0f; cur.av0 = 1.0f; cur.av1 = 0.0f;
+        cur.calc = 0.0f; cur.real_u = 1u; cur.has_calc = 0u; cur.times = 0u;
+        sp = 0u;
+        best_t = SPT_F32_MAX;
+        found = false;
+        finished = false;
+    }
+    // one call of bezier_clipping (bezier.rs:239-422)
+    SPT_DEV void step(BzFrame* stack) {
+        bool descend = false;   // true: `cur` was replaced by a child and is processed next
+        if (cur.times == kClippingMaxTimes) {
+            const float u = 0.5f * cur.au0 + cur.au1;
+            const float v = cur.has_calc ? cur.calc : 0.5f * cur.av0 + cur.av1;
+            if (cur.real_u) candidate(u, v); else candidate(v, u);
+        } else {
+            float upper[4], lower[4];
+            for (int j = 0; j < 4; ++j) {
+                upper[j] = 0.0f; lower[j] = 0.0f;
+                for (int i = 0; i < 4; ++i) {
+                    const float dist = cur.p[i][j].x * cur.lu.y - cur.p[i][j].y * cur.lu.x;
+                    if (i == 0 || dist > upper[j]) upper[j] = dist;
+                    if (i == 0 || dist < lower[j]) lower[j] = dist;
+                }
+            }
+            float u_min = (upper[0] >= 0.0f && lower[0] <= 0.0f) ? 0.0f : 1.0f;
+            float u_max = (upper[3] >= 0.0f && lower[3] <= 0.0f) ? 1.0f : 0.0f;
+            for (int a = 0; a < 3; ++a)
+                for (int b = a + 1; b < 4; ++b) {   // pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+                    if (upper[a] * upper[b] <= 0.0f) {
+                        const float diff = upper[b] - upper[a];
+                        if (diff == 0.0f) {
+                            u_min = spt_min(u_min, (float)a / 3.0f);
+                            u_max = spt_max(u_max, (float)b / 3.0f);
+                        } else {
+                            const float k = (float)(b - a) / 3.0f / diff;
+                            const float c = (float)a / 3.0f - k * upper[a];
+                            u_min = spt_min(u_min, c);
+                            u_max = spt_max(u_max, c);
+                        }
+                    }
+                    if (lower[a] * lower[b] <= 0.0f) {
+                        const float diff = lower[b] - lower[a];
+                        if (diff == 0.0f) {
+                            u_min = spt_min(u_min, (float)a / 3.0f);
+                            u_max = spt_max(u_max, (float)b / 3.0f);
+                        } else {
+                            const float k = (float)(b - a) / 3.0f / diff;
+                            const float c = (float)b / 3.0f - k * lower[b];
+                            u_min = spt_min(u_min, c);
+                            u_max = spt_max(u_max, c);
+                        }
+                    }
+                }
+            if (!(u_max < u_min)) {
+                const bool swap = cur.has_calc == 0u;
+                if (u_max - u_min > 0.8f) {
+                    // both halves: the right one waits on the stack
+                    v2 l[4][4], r[4][4];
+                    for (int k = 0; k < 4; ++k) clip_bezier_at_midpoint(cur.p[k], l[k], r[k]);
+                    BzFrame& right = stack[sp++];
+                    const float half = cur.au0 * 0.5f;
+                    if (swap) {
+                        for (int a = 0; a < 4; ++a)
+                            for (int b = 0; b < 4; ++b) { right.p[a][b] = r[b][a]; }
+                        right.lu = cur.lv; right.lv = cur.lu;
+                        right.au0 = cur.av0; right.au1 = cur.av1; right.av0 = half; right.av1 = half + cur.au1;
+                        right.real_u = cur.real_u ^ 1u; right.has_calc = 0u; right.calc = 0.0f;
+                        right.times = cur.times + 1u;
+                        BzFrame left;
+                        for (int a = 0; a < 4; ++a)
+                            for (int b = 0; b < 4; ++b) left.p[a][b] = l[b][a];
+                        left.lu = cur.lv; left.lv = cur.lu;
+                        left.au0 = cur.av0; left.au1 = cur.av1; left.av0 = half; left.av1 = cur.au1;
+                        left.real_u = cur.real_u ^ 1u; left.has_calc = 0u; left.calc = 0.0f;
+                        left.times = cur.times + 1u;
+                        cur = left;
+                    } else {
+                        for (int a = 0; a < 4; ++a)
+                            for (int b = 0; b < 4; ++b) right.p[a][b] = r[a][b];
+                        right.lu = cur.lu; right.lv = cur.lv;
+                        right.au0 = half; right.au1 = half + cur.au1; right.av0 = cur.av0; right.av1 = cur.av1;
+                        right.real_u = cur.real_u; right.has_calc = cur.has_calc; right.calc = cur.calc;
+                        right.times = cur.times + 1u;
+                        for (int a = 0; a < 4; ++a)
+                            for (int b = 0; b < 4; ++b) cur.p[a][b] = l[a][b];
+                        cur.au0 = half;
+                        cur.times += 1u;
+                    }
+                    descend = true;
+                } else {
+                    const float u_len = u_max - u_min;
+                    const bool stop = u_len * cur.au0 < kClippingEps;
+                    bool finished = false;
+                    if (stop) {
+                        const float u = 0.5f * (u_max + u_min) * cur.au0 + cur.au1;
+                        if (cur.has_calc) {
+                            if (cur.real_u) candidate(u, cur.calc); else candidate(cur.calc, u);
+                            finished = true;
+                        } else {
+                            cur.has_calc = 1u;
+                            cur.calc = u;
+                        }
+                    }
+                    if (!finished) {
+                        v2 n[4][4];
+                        for (int k = 0; k < 4; ++k) clip_bezier_by(cur.p[k], u_min, u_max, n[k]);
+                        const float na0 = cur.au0 * u_len, na1 = cur.au0 * u_min + cur.au1;
+                        if (swap) {
+                            for (int a = 0; a < 4; ++a)
+                                for (int b = 0; b < 4; ++b) cur.p[a][b] = n[b][a];
+                            const v2 t = cur.lu; cur.lu = cur.lv; cur.lv = t;
+                            cur.au0 = cur.av0; cur.au1 = cur.av1; cur.av0 = na0; cur.av1 = na1;
+                            cur.real_u ^= 1u;
+                        } else {
+                            for (int a = 0; a < 4; ++a)
+                                for (int b = 0; b < 4; ++b) cur.p[a][b] = n[a][b];
+                            cur.au0 = na0; cur.au1 = na1;
+                        }
+                        cur.times += 1u;
+                        descend = true;
+                    }
+                }
+            }
+        }
+        if (descend) return;
+        if (sp == 0u) { finished = true; return; }
+        cur = stack[--sp];
+    }
+};
+
+
 #endif  // SPT_WITH_BEZIER

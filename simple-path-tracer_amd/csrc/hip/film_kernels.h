@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(256) k_trace_closest_stream(DScene sc, uint32_
         r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
         wk.begin(sc, r, rays[i].t_max);
     }
-    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem);
+    BezDefer no_defer{nullptr, nullptr, 0u, 0u, 0u};   // the ray seams test every patch where they meet it
+    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem, no_defer);
     if (i >= n) return;
     const bool hit = wk.h.inst >= 0;
     hits[i].t = hit ? wk.h.t : SPT_F32_MAX;
@@ -194,7 +195,8 @@ __global__ void __launch_bounds__(256) k_trace_any_stream(DScene sc, uint32_t n,
         r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
         wk.begin(sc, r, rays[i].t_max);
     }
-    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem);
+    BezDefer no_defer{nullptr, nullptr, 0u, 0u, 0u};   // the ray seams test every patch where they meet it
+    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem, no_defer);
     if (i < n) occluded[i] = wk.h.inst >= 0 ? 1 : 0;
 }
 

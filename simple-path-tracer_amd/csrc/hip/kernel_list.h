@@ -81,6 +81,18 @@
     X((k_trace_wst<WstShadow, false>), SPT_ARGS_WST)    \
     X((k_trace_wst<WstShadow, true>), SPT_ARGS_WST)
 
+// deferred patch tests (bezier_pairs.h)
+#if SPT_WITH_BEZIER
+#define SPT_KERNELS_BEZ(X)                                                            \
+    X((k_bezier_pairs<false>), (DScene, BezPairs))                                    \
+    X((k_bezier_pairs<true>), (DScene, BezPairs))                                     \
+    X((k_bezier_commit<0>), (BezPairs))                                               \
+    X((k_bezier_finish_shadow<0>), (RenderCtx, BezPairs))                             \
+    X((k_bezier_finish_extend<0>), (DScene, RenderCtx, BezPairs, uint32_t))
+#else
+#define SPT_KERNELS_BEZ(X)
+#endif
+
 #if defined(SPT_INSTANTIATE_GROUP_PRIMARY)
 SPT_KERNELS_PRIMARY(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_RAYS)
@@ -89,6 +101,7 @@ SPT_KERNELS_RAYS(SPT_DEFINE_KERNEL)
 SPT_KERNELS_WST(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_STREAM)
 SPT_KERNELS_STREAM(SPT_DEFINE_KERNEL)
+SPT_KERNELS_BEZ(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE0)
 SPT_KERNELS_SHADE0(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE1)
@@ -103,6 +116,7 @@ SPT_KERNELS_SHADE3B(SPT_DEFINE_KERNEL)
 SPT_KERNELS_PRIMARY(SPT_DECLARE_KERNEL)
 SPT_KERNELS_RAYS(SPT_DECLARE_KERNEL)
 SPT_KERNELS_STREAM(SPT_DECLARE_KERNEL)
+SPT_KERNELS_BEZ(SPT_DECLARE_KERNEL)
 SPT_KERNELS_WST(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE0(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE1(SPT_DECLARE_KERNEL)

@@ -112,6 +112,7 @@ struct RenderCtx {
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
     uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
+    BezPairs bzs, bze;                      // deferred patch tests of the shadow / extension rays (bezier_pairs.h; rec == null: off)
 };
 
 SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -983,6 +984,7 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
     wk.cur = kNoRef;
     bool busy = false, drained = false;
     uint32_t idx = 0;
+    BezDefer bd{rc.bzs.rec, rc.bzs.ctl, rc.bzs.cap, 0u, 0u};    // (null in the plain library and when deferral is off)
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
     for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
@@ -994,20 +996,35 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
                 DRay r;
                 r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
                 wk.begin(sc, r, b.w);
+                bd.ray = idx; bd.pushed = 0u;
                 busy = true;
             }
             // the cursor only grows: once any lane was refused the shard is empty for good
             drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
         }
         if (__ballot(busy) == 0ull) break;
-        wk.run(sc, rc.stream_rounds, spill_mem);
+        wk.run(sc, rc.stream_rounds, spill_mem, bd);
+        bool defer = false;
         if (busy && wk.done) {
-            if (wk.h.inst < 0) {  // not occluded
-                const float4 c = rc.shadow.contrib_slot[idx];
-                rad_add(rc, __float_as_uint(c.w), mk3(c));
+            if (wk.h.inst < 0) {  // not occluded (by anything but the patches whose tests were parked)
+                if (SPT_WITH_BEZIER && bd.pushed != 0u) {
+                    defer = true;
+                } else {
+                    const float4 c = rc.shadow.contrib_slot[idx];
+                    rad_add(rc, __float_as_uint(c.w), mk3(c));
+                }
             }
             busy = false;
         }
+#if SPT_WITH_BEZIER
+        if (rc.bzs.rec != nullptr) {     // (wave-uniform) the ray waits for its pairs: k_bezier_finish_shadow adds its term or not
+            const uint32_t j = wave_push(defer, rc.bzs.ctl + 2u + shard);
+            if (defer) {
+                rc.bzs.occluded[idx] = 0;
+                rc.bzs.def_list[(size_t)qbase + j] = idx;
+            }
+        }
+#endif
     }
     if (kCount) flush_visits(rc, wk.vc, 1u);
 }
@@ -1026,6 +1043,7 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
     wk.cur = kNoRef;
     bool busy = false, drained = false, in_medium = false;
     uint32_t idx = 0;
+    BezDefer bd{rc.bze.rec, rc.bze.ctl, rc.bze.cap, 0u, 0u};    // (null in the plain library and when deferral is off)
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
     for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
@@ -1038,14 +1056,29 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
                 DRay r;
                 r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
                 wk.begin(sc, r, SPT_F32_MAX);
+                bd.ray = idx; bd.pushed = 0u;
                 busy = true;
             }
             drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
         }
         if (__ballot(busy) == 0ull) break;
-        wk.run(sc, rc.stream_rounds, spill_mem);
-        const bool retire = busy && wk.done;
+        wk.run(sc, rc.stream_rounds, spill_mem, bd);
+        bool retire = busy && wk.done;
         bool keep = false;
+#if SPT_WITH_BEZIER
+        if (rc.bze.rec != nullptr) {     // (wave-uniform) a ray with parked patch tests leaves what the walk found and waits:
+            const bool defer = retire && bd.pushed != 0u;      // k_bezier_finish_extend ends it
+            const uint32_t j = wave_push(defer, rc.bze.ctl + 2u + shard);
+            if (defer) {
+                rc.bze.def_hit[idx] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
+                rc.bze.def_inst[idx] = wk.h.inst;
+                rc.bze.key[idx] = ~0ull;
+                rc.bze.def_list[(size_t)qbase + j] = idx;
+                busy = false;
+                retire = false;
+            }
+        }
+#endif
         if (retire) {
             if (wk.h.inst >= 0 || in_medium) {
                 keep = true;
@@ -1095,6 +1128,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
     const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
     const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
     uint2 spill_mem[kSpillStack];
+    BezDefer no_defer{nullptr, nullptr, 0u, 0u, 0u};   // camera rays test a patch where they meet it (coherent: the walker is full)
     SWalker<true, kCount> wk;
     wk.vc = LaneVisits{0u, 0u, 0u};
     wk.done = true;
@@ -1136,7 +1170,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
             }
         }
         if (__ballot(busy) == 0ull) break;
-        wk.run(sc, rc.stream_rounds, spill_mem);
+        wk.run(sc, rc.stream_rounds, spill_mem, no_defer);
         const bool retire = busy && wk.done;
         const bool hit = retire && wk.h.inst >= 0;
         const size_t ri = (size_t)s_cur * rc.n_pixels + lp;
@@ -1182,3 +1216,4 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
 }
 
 #include "wst.h"   // kind-sorted traversal (uses the queue / context definitions above)
+#include "bezier_pairs.h"   // deferred patch tests (Bezier library only)

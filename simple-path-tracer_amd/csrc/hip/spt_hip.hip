@@ -507,6 +507,8 @@ struct spt_scene {
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, slot_bits, out;
     DeviceBuffer trace_in, trace_out, visits, wst_ovf;
+    // deferred patch tests (bezier_pairs.h; the Bezier library only): [0] shadow rays, [1] extension rays
+    DeviceBuffer bz_rec[2], bz_ctl[2], bz_def_list[2], bz_occluded, bz_def_hit, bz_def_inst, bz_key, bz_def_uv;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
@@ -1421,6 +1423,34 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.stream_rounds = std::max(1u, std::min(255u, env_u32("SPT_STREAM_ROUNDS", 4u))) | (env_u32("SPT_STREAM_IFIF", 1u) ? 0x100u : 0u);
             rc.stream_refill_below = env_u32("SPT_STREAM_REFILL", 40u);
             rc.visits = sc->visits.as<unsigned long long>();
+#if SPT_WITH_BEZIER
+            // SPT_BEZ_DEFER=1: the patch tests of the shadow / extension rays leave the streaming walkers for a clipping kernel
+            // of their own (bezier_pairs.h).  Opt-in: bit-identical, and MEASURED slower than testing a patch where the walker
+            // meets it (t_bezier.json 146 vs 132 ms, t_catmull.json 235 vs 177 ms; why: profiles/r02_experiments.md)
+            if (sc->swalk && !sc->lds_geo && sc->d.bez != nullptr && std::getenv("SPT_BEZ_DEFER") != nullptr) {
+                const size_t pairs_cap = (size_t)std::min<uint64_t>(4ull * cap, 1ull << 28);
+                for (int k = 0; k < 2; ++k) {
+                    sc->bz_rec[k].ensure(pairs_cap * 48);
+                    sc->bz_ctl[k].ensure((2 + kShards) * sizeof(uint32_t));
+                    sc->bz_def_list[k].ensure(cap * sizeof(uint32_t));
+                }
+                sc->bz_occluded.ensure(cap);
+                sc->bz_def_hit.ensure(cap * 16);
+                sc->bz_def_inst.ensure(cap * 4);
+                sc->bz_key.ensure(cap * 8);
+                sc->bz_def_uv.ensure(cap * 16);
+                BezPairs bp{};
+                bp.cap = (uint32_t)pairs_cap;
+                bp.occluded = sc->bz_occluded.as<uint8_t>();
+                bp.def_hit = sc->bz_def_hit.as<float4>();
+                bp.def_inst = sc->bz_def_inst.as<int32_t>();
+                bp.key = sc->bz_key.as<unsigned long long>();
+                bp.def_uv = sc->bz_def_uv.as<float4>();
+                rc.bzs = bp; rc.bze = bp;
+                rc.bzs.rec = sc->bz_rec[0].as<float4>(); rc.bzs.ctl = sc->bz_ctl[0].as<uint32_t>(); rc.bzs.def_list = sc->bz_def_list[0].as<uint32_t>();
+                rc.bze.rec = sc->bz_rec[1].as<float4>(); rc.bze.ctl = sc->bz_ctl[1].as<uint32_t>(); rc.bze.def_list = sc->bz_def_list[1].as<uint32_t>();
+            }
+#endif
             // tiles of this shard that intersect the screen-space bound (all of them with an environment)
             uint32_t active_tiles = pix_blocks;
             uint64_t live_pixels = n_pix;
@@ -1549,6 +1579,15 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     begin(SPT_K_SHADOW);
                     if ((wst_mask & 1u) && count) hipLaunchKernelGGL((k_trace_wst<WstShadow, true>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, ss, sc->d, ru, b, sc->wst_ovf.as<uint2>());
                     else if (wst_mask & 1u) hipLaunchKernelGGL((k_trace_wst<WstShadow, false>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, ss, sc->d, ru, b, sc->wst_ovf.as<uint2>());
+#if SPT_WITH_BEZIER
+                    else if (stream_s && ru.bzs.rec != nullptr) {      // walk, clip the parked (ray, patch) pairs, end the rays that waited
+                        HIP_CHECK(hipMemsetAsync(ru.bzs.ctl, 0, (2 + kShards) * sizeof(uint32_t), ss));
+                        if (count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                        else hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                        hipLaunchKernelGGL(k_bezier_pairs<false>, dim3(kDynBlocks), dim3(kBlock), 0, ss, sc->d, ru.bzs);
+                        hipLaunchKernelGGL(k_bezier_finish_shadow<0>, dim3(kPersistentBlocks), dim3(kBlock), 0, ss, ru, ru.bzs);
+                    }
+#endif
                     else if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (stream_s) hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
@@ -1562,6 +1601,16 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         begin(SPT_K_EXTEND);
                         if ((wst_mask & 2u) && count) hipLaunchKernelGGL((k_trace_wst<WstExtend, true>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, st, sc->d, ru, b, sc->wst_ovf.as<uint2>());
                         else if (wst_mask & 2u) hipLaunchKernelGGL((k_trace_wst<WstExtend, false>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, st, sc->d, ru, b, sc->wst_ovf.as<uint2>());
+#if SPT_WITH_BEZIER
+                        else if (stream_e && ru.bze.rec != nullptr) {
+                            HIP_CHECK(hipMemsetAsync(ru.bze.ctl, 0, (2 + kShards) * sizeof(uint32_t), st));
+                            if (count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                            else hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                            hipLaunchKernelGGL(k_bezier_pairs<true>, dim3(kDynBlocks), dim3(kBlock), 0, st, sc->d, ru.bze);
+                            hipLaunchKernelGGL(k_bezier_commit<0>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, ru.bze);
+                            hipLaunchKernelGGL(k_bezier_finish_extend<0>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, ru, ru.bze, b);
+                        }
+#endif
                         else if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (stream_e) hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);

@@ -165,6 +165,8 @@ SWITCHES = [
     {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3"},                               # kind-sorted traversal (wst.h) for shadow and extension rays
     {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3", "SPT_REFERENCE_BVH": "1"},
     {"SPT_NO_TAIL_LOOP": "1"},                                                  # fused scenes: one launch per bounce even when few paths are left
+    {"SPT_BEZ_DEFER": "1"},                                                     # patch scenes: (ray, patch) pairs clipped by a kernel of their own
+    {"SPT_BEZ_DEFER": "1", "SPT_STREAM_MASK": "7"},
     {"SPT_NO_PIXEL_CULL": "1"},
     {"SPT_NO_OVERLAP": "1"},
     {"SPT_PRIMARY_CHUNKS": "1"},
@@ -176,7 +178,7 @@ ALL_SWITCHES = sorted({k for s in SWITCHES for k in s})
 
 
 @pytest.mark.parametrize("switch", SWITCHES, ids=lambda s: "+".join("%s=%s" % kv for kv in sorted(s.items())))
-@pytest.mark.parametrize("scene_name,camera", [("cfg2_cube.json", None), ("t_materials.json", "main"), ("t_medium.json", None)])
+@pytest.mark.parametrize("scene_name,camera", [("cfg2_cube.json", None), ("t_materials.json", "main"), ("t_medium.json", None), ("t_bezier.json", "low")])
 def test_switch_sweep(spt, scene_name, camera, switch, monkeypatch):
     for k in ALL_SWITCHES:
         monkeypatch.delenv(k, raising=False)

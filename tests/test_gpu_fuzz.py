@@ -49,6 +49,6 @@ def test_random_scene_with_round2_features_matches_oracle(fuzz, seed, monkeypatc
     finally:
         for name in ("SPT_NO_FUSED", "SPT_NO_LDS_TABLES", "SPT_NO_LDS_GEO", "SPT_NO_PIXEL_CULL", "SPT_NO_OVERLAP", "SPT_NO_DYN_SHADOW", "SPT_NO_DYN_EXTEND",
                      "SPT_PRIMARY_CHUNKS", "SPT_BOX_BAND_BYTES", "SPT_BVH_MAX_LEAF", "SPT_DYN_BLOCKS", "SPT_NO_TAIL_LOOP", "SPT_NO_STREAM", "SPT_STREAM_MASK",
-                     "SPT_STREAM_IFIF", "SPT_WST_MASK", "SPT_BEZ_LDS"):
+                     "SPT_STREAM_IFIF", "SPT_WST_MASK", "SPT_BEZ_LDS", "SPT_BEZ_DEFER"):
             os.environ.pop(name, None)       # run_seed sets the switches it drew in the process environment
     assert ok, info
