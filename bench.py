@@ -334,7 +334,8 @@ def main():
                 break
         if traffic_file and world == 1 and args.samples_per_pass == 0 and args.spp == 256:
             tk = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["kernels"].get("k_" + dom_name)   # "k_shade_first": bounce-0 instances
-            if tk and tk["launches"] == dom.get("launches_per_step"):   # (per-template-instance entries: see tools/pmc_traffic.py)
+            # (the PMC run renders the step a few times: its launch count is a multiple of the step's when the pass layout is the same)
+            if tk and dom.get("launches_per_step") and tk["launches"] % dom["launches_per_step"] == 0:
                 traffic = round(tk["hbm_bytes_per_launch"] / 1e6, 3)
         roofline = {
             "bound": "hbm", "kernel": RNAME.get(dom_name, "k_" + dom_name) + (" (bounce 0)" if dom_name == "shade_first" else ""), "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
