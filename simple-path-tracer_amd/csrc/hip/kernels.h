@@ -1005,6 +1005,7 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
         if (__ballot(busy) == 0ull) break;
         wk.run(sc, rc.stream_rounds, spill_mem, bd);
         bool defer = false;
+        (void)defer;
         if (busy && wk.done) {
             if (wk.h.inst < 0) {  // not occluded (by anything but the patches whose tests were parked)
                 if (SPT_WITH_BEZIER && bd.pushed != 0u) {
