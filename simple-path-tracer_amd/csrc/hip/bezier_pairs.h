@@ -23,8 +23,9 @@
 // MEASURED (round 2, 512^2 @ 64 spp): the walking kernels drop from 110 ms to 13 ms (t_bezier.json) - and the clipping kernel
 // takes 108 ms: it runs at 27 % lane utilisation even with every lane holding a pair (the twelve hull-crossing tests, the
 // split / clip / stop paths and the 1 - 40 calls per test diverge INSIDE the clipping), at 1 - 2 waves per SIMD (253 - 265
-// VGPRs), and moves 42 GB of frame pushes / pops through scratch per render.  Total 146 ms against 132 ms inline
-// (t_catmull.json: 235 against 177 ms - without the pruning by closer patch hits its rays meet twice as many patches).  So
+// VGPRs), and moves 42 GB of frame pushes / pops through scratch per render.  Total 146 ms as first built, 132 ms with the
+// refill cadence and occupancy below (each measured), against 130 ms inline (t_catmull.json: 196 against 181 ms - without
+// the pruning by closer patch hits its rays meet 1.6 x as many patches).  So
 // the design the round-1 review asked for is here, bit-identical (switch sweep, fuzz seeds), and OFF by default
 // (SPT_BEZ_DEFER=1 turns it on).  What it needs next is a clipping step that keeps < 128 registers live.
 //
@@ -46,12 +47,15 @@ SPT_DEV bool bez_defer_push(BezDefer& bd, const DRay& orr, float limit, uint32_t
     return true;
 }
 
-constexpr uint32_t kBezRefillBelow = 56;   // refill the wave when fewer lanes than this still clip
-constexpr uint32_t kBezSteps = 2;          // clipping calls between two retire / refill checks
+#ifndef SPT_W_BEZ
+#define SPT_W_BEZ 2
+#endif
+constexpr uint32_t kBezRefillBelow = 32;   // refill the wave when fewer lanes than this still clip
+constexpr uint32_t kBezSteps = 8;          // clipping calls between two retire / refill checks
 
 // Persistent waves over the pair queue.  kClosest: extension rays (best candidate per ray), else shadow rays (a flag).
 template <bool kClosest>
-__global__ void __launch_bounds__(256) k_bezier_pairs(DScene sc, BezPairs bp) {
+__global__ void __launch_bounds__(256, SPT_W_BEZ) k_bezier_pairs(DScene sc, BezPairs bp) {
     const uint32_t n = min(bp.ctl[0], bp.cap);
     uint32_t* cursor = bp.ctl + 1;
     BzFrame stack[kClippingMaxTimes];

@@ -1426,7 +1426,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
 #if SPT_WITH_BEZIER
             // SPT_BEZ_DEFER=1: the patch tests of the shadow / extension rays leave the streaming walkers for a clipping kernel
             // of their own (bezier_pairs.h).  Opt-in: bit-identical, and MEASURED slower than testing a patch where the walker
-            // meets it (t_bezier.json 146 vs 132 ms, t_catmull.json 235 vs 177 ms; why: profiles/r02_experiments.md)
+            // meets it (t_bezier.json 132 vs 130 ms, t_catmull.json 196 vs 181 ms; why: profiles/r02_experiments.md)
             if (sc->swalk && !sc->lds_geo && sc->d.bez != nullptr && std::getenv("SPT_BEZ_DEFER") != nullptr) {
                 const size_t pairs_cap = (size_t)std::min<uint64_t>(4ull * cap, 1ull << 28);
                 for (int k = 0; k < 2; ++k) {
