@@ -150,14 +150,33 @@ void build_sah_blas(const spt_tri_pos* tris, uint32_t tri_first, uint32_t tri_co
     build_sah(t, tri_first, max_leaf, traversal_cost, nodes, order, "BLAS");
 }
 
+// CubicBezier::intersect_ray ACCEPTS a candidate point of the patch that lies within a tolerance of the ray
+// (|cross(p - o, d)|^2 < 1e-5 in the patch's object space, bezier.rs:121-131), so a ray that misses the hull of the control
+// points by a hair can still "hit" - and the hit's t can lie a hair in front of the box.  Which of those near misses a
+// walker sees would then depend on how tight its boxes are and on the order of its visits (fuzz seeds 3017 / 3034 of round
+// 2: the streaming walker's quantised boxes against the padded ones, one or two pixels per 600 k samples).  Every box this
+// library culls a patch with is therefore widened by the largest distance, in world space, at which the test can
+// accept: sqrt(1e-5) over the smallest singular value of cof(M^-1) = sqrt(1e-5) * s1 * s2 (the two largest stretches of
+// the instance's M), bounded here by |M|_F^2 / 2.  With that, "tested" is a superset of "can be accepted" for every walker,
+// and all of them return what testing every patch returns.  (SPT_REFERENCE_BVH=1 keeps the caller's exact boxes and the
+// reference's visit order: that mode reproduces the reference's own loss of such hits.)
+float bezier_box_margin(const spt_instance& in) {
+    if (in.prim_type != SPT_PRIM_BEZIER) return 0.0f;
+    double f2 = 0.0;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) f2 += (double)in.fwd[3 * c + r] * (double)in.fwd[3 * c + r];   // the 3 x 3 part (columns), not the translation
+    return (float)(0.0031623 * 1.02 * 0.5 * f2 + 1e-6);
+}
+
 // The same builder over the instances' world boxes: the device-side TLAS.  An instance visit (transform the ray, walk
 // a BLAS) costs far more than a node visit, so leaves hold one instance unless the split is useless.
 void build_sah_tlas(const spt_instance* inst, uint32_t n, std::vector<spt_bvh_node>& nodes, std::vector<uint32_t>& order) {
     std::vector<SahTri> t(n);
     for (uint32_t i = 0; i < n; ++i) {
+        const float margin = bezier_box_margin(inst[i]);
         for (int k = 0; k < 3; ++k) {
-            t[i].lo[k] = inst[i].bmin[k];
-            t[i].hi[k] = inst[i].bmax[k];
+            t[i].lo[k] = inst[i].bmin[k] - margin;
+            t[i].hi[k] = inst[i].bmax[k] + margin;
             t[i].c[k] = 0.5f * (t[i].lo[k] + t[i].hi[k]);
         }
         t[i].id = i;
@@ -990,6 +1009,8 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                             else if (in.prim_type == SPT_PRIM_SPHERE) { const spt_sphere& sp = s.spheres[in.prim_id]; r[4] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius); }
                         }
                         sc->swalk = std::getenv("SPT_NO_STREAM") == nullptr;
+                        // (patches under the caller's exact boxes: only the reference's visit order reproduces which near misses it loses)
+                        if (!own_bvh && s.n_bezier_patches != 0) sc->swalk = false;
                     } catch (const AbiError&) {
                         wblas.resize(blas_f4);   // e.g. an instance box too large to quantise: the walkers of trace.h serve the scene
                         sinst.clear();
@@ -1153,12 +1174,14 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         if (s.n_instances) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             bool finite = true;
-            for (uint32_t i = 0; i < s.n_instances; ++i)
+            for (uint32_t i = 0; i < s.n_instances; ++i) {
+                const double margin = bezier_box_margin(s.instances[i]);   // the screen-space bound and the bounding sphere cull too
                 for (int k = 0; k < 3; ++k) {
-                    lo[k] = std::min(lo[k], (double)s.instances[i].bmin[k]);
-                    hi[k] = std::max(hi[k], (double)s.instances[i].bmax[k]);
+                    lo[k] = std::min(lo[k], (double)s.instances[i].bmin[k] - margin);
+                    hi[k] = std::max(hi[k], (double)s.instances[i].bmax[k] + margin);
                     finite = finite && std::isfinite(s.instances[i].bmin[k]) && std::isfinite(s.instances[i].bmax[k]);
                 }
+            }
             double r2 = 0;
             for (int k = 0; k < 3; ++k) {
                 sc->bs_center[k] = 0.5 * (lo[k] + hi[k]);

@@ -184,10 +184,18 @@ struct SWalker {
         const uint32_t qnz = nz ? qhz : qlz, qfz = nz ? qlz : qhz;
         float key[4];
         uint32_t ref[4] = {__float_as_uint(n2.z), __float_as_uint(n2.w), __float_as_uint(n3.x), __float_as_uint(n3.y)};
+        // The relative relaxation covers the rounding of a distance of its own size.  q * s + a, however, is the sum of two
+        // terms that can each be far larger than the distance (a ray that grazes a slab from inside the node: a = (p - o) / d
+        // and q * s = (plane - p) / d cancel), and its error is an ulp of THOSE: a plane at distance ~0 could come out at
+        // +2e-3 for 1 / d = 1e4 and cull a node whose hit lies closer than that (fuzz seed 3034 of round 2: two pixels of a
+        // scene with surfaces resting on each other).  So the interval is also widened by an absolute bound on that error,
+        // 2^-22 of the largest |a| + 255 |s| of the three axes, once per node.
+        const float eabs = max3f(__builtin_fabsf(ax) + 255.0f * __builtin_fabsf(sx), __builtin_fabsf(ay) + 255.0f * __builtin_fabsf(sy),
+                                 __builtin_fabsf(az) + 255.0f * __builtin_fabsf(sz)) * 2.3841858e-7f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float t0 = max3f(__builtin_fmaf(ubyte_f32(qnx, c), sx, ax), __builtin_fmaf(ubyte_f32(qny, c), sy, ay), __builtin_fmaf(ubyte_f32(qnz, c), sz, az)) * kRelaxLo;
-            const float t1 = min3f(__builtin_fmaf(ubyte_f32(qfx, c), sx, ax), __builtin_fmaf(ubyte_f32(qfy, c), sy, ay), __builtin_fmaf(ubyte_f32(qfz, c), sz, az)) * kRelaxHi;
+            const float t0 = max3f(__builtin_fmaf(ubyte_f32(qnx, c), sx, ax), __builtin_fmaf(ubyte_f32(qny, c), sy, ay), __builtin_fmaf(ubyte_f32(qnz, c), sz, az)) * kRelaxLo - eabs;
+            const float t1 = min3f(__builtin_fmaf(ubyte_f32(qfx, c), sx, ax), __builtin_fmaf(ubyte_f32(qfy, c), sy, ay), __builtin_fmaf(ubyte_f32(qfz, c), sz, az)) * kRelaxHi + eabs;
             const bool hit = ((uint32_t)c < n_child) & (t0 <= t1) & (t1 > t_min) & passes(t0);
             key[c] = hit ? t0 : spt_inf();
         }

@@ -164,10 +164,13 @@ struct WstRay {
         const uint32_t qnz = nz ? qhz : qlz, qfz = nz ? qlz : qhz;
         float key[4];
         uint32_t ref[4] = {__float_as_uint(n2.z), __float_as_uint(n2.w), __float_as_uint(n3.x), __float_as_uint(n3.y)};
+        // (absolute bound on the rounding of q * s + a: see SWalker::node_step in stream.h)
+        const float eabs = max3f(__builtin_fabsf(ax) + 255.0f * __builtin_fabsf(sx), __builtin_fabsf(ay) + 255.0f * __builtin_fabsf(sy),
+                                 __builtin_fabsf(az) + 255.0f * __builtin_fabsf(sz)) * 2.3841858e-7f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float t0 = max3f(__builtin_fmaf(ubyte_f32(qnx, c), sx, ax), __builtin_fmaf(ubyte_f32(qny, c), sy, ay), __builtin_fmaf(ubyte_f32(qnz, c), sz, az)) * kRelaxLo;
-            const float t1 = min3f(__builtin_fmaf(ubyte_f32(qfx, c), sx, ax), __builtin_fmaf(ubyte_f32(qfy, c), sy, ay), __builtin_fmaf(ubyte_f32(qfz, c), sz, az)) * kRelaxHi;
+            const float t0 = max3f(__builtin_fmaf(ubyte_f32(qnx, c), sx, ax), __builtin_fmaf(ubyte_f32(qny, c), sy, ay), __builtin_fmaf(ubyte_f32(qnz, c), sz, az)) * kRelaxLo - eabs;
+            const float t1 = min3f(__builtin_fmaf(ubyte_f32(qfx, c), sx, ax), __builtin_fmaf(ubyte_f32(qfy, c), sy, ay), __builtin_fmaf(ubyte_f32(qfz, c), sz, az)) * kRelaxHi + eabs;
             const bool hit = ((uint32_t)c < n_child) & (t0 <= t1) & (t1 > t_min) & passes(t0);
             key[c] = hit ? t0 : spt_inf();
         }
