@@ -1032,7 +1032,10 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             if (std::getenv("SPT_NO_LDS_GEO")) sc->lds_geo = false;   // tests: drive small scenes through the large-scene path
             // patches: the streaming walkers of the large-scene path refill lanes whose patch test is over (measured,
             // t_bezier.json 512^2 @ 64 spp: 177 ms LDS-resident nested walkers, 147 ms here; SPT_BEZ_LDS=1 for the former)
-            if (SPT_WITH_BEZIER && std::getenv("SPT_BEZ_LDS") == nullptr) sc->lds_geo = false;
+            // (not under SPT_REFERENCE_BVH=1: only the exact 2-wide nodes in the reference's visit order reproduce which near
+            //  misses of a patch the reference's own culling loses - see bezier_box_margin; the compressed 4-wide form of
+            //  the caller's trees, which serves scenes beyond LDS in that mode, can differ from it in such a pixel)
+            if (SPT_WITH_BEZIER && own_bvh && std::getenv("SPT_BEZ_LDS") == nullptr) sc->lds_geo = false;
             if (!sc->lds_geo) assemble(true);
             // fused bounces (k_shade<0, ., kFused>): LDS-resident geometry + the lean simple-scene shade kernel, and
             // the shading tables must fit behind the geometry too (see tab_ld in shading.h)

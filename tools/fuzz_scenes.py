@@ -268,6 +268,8 @@ def run_seed(seed, work):
             os.environ.pop(name, None)
             if rng.random() < 0.25:
                 switches[name] = values[int(rng.integers(0, len(values)))]
+        if os.environ.get("SPT_REFERENCE_BVH") and (any(p["type"] in ("cubic_bezier", "catmull_clark") for p in scene["primitives"])):
+            switches.pop("SPT_NO_LDS_GEO", None)     # patches + the caller's trees: only the exact LDS-resident nodes follow the reference's culling
         os.environ.update(switches)
     try:
         sc = spt.load_scene(path)
@@ -293,7 +295,7 @@ def run_seed(seed, work):
         nan = np.isnan(ref)
         same_nan = np.array_equal(nan, np.isnan(got))
         diff = int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum())
-        if (diff or not same_nan) and flags != _util.device_oracle_flags():
+        if (diff or not same_nan) and flags != _util.device_oracle_flags() and not os.environ.get("SPT_REFERENCE_BVH"):
             # the stand-in oracle walks the caller's EXACT boxes and can lose a grazing hit that the library's padded trees
             # keep (seed 625 of the round-2 campaign: one pixel): such a film is settled by the exhaustive oracle
             ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags(), shard_index=k, shard_count=shard_count, strip_rows=strip_rows)
