@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 11
+#define SPT_ABI_VERSION 12
 
 typedef int32_t spt_status;
 enum {
@@ -87,8 +87,12 @@ typedef struct spt_mesh {     /* one TriMesh = one BLAS (src/primitive/triangle.
     uint32_t tri_count;
 } spt_mesh;
 
-/* One bicubic Bezier patch (src/primitive/bezier.rs:19-22): cp[i][j] = control_points[i][j] (xyz, w unused);
- * point_at(u, v) = sum_ij B_j(u) B_i(v) cp[i][j] (bezier.rs:40-44, 222-236).  The instance's box is the hull's. */
+/* One bicubic Bezier patch (src/primitive/bezier.rs:19-22): cp[i][j] = control_points[i][j] (xyz; w unused, except:)
+ * point_at(u, v) = sum_ij B_j(u) B_i(v) cp[i][j] (bezier.rs:40-44, 222-236).  The instance's box is the hull's.
+ * ABI v12: cp[0][0][3] selects the intersection routine, as the reference's Cargo feature `bezier_ni` does at compile time
+ * (Cargo.toml:34-36): 0 = Bezier clipping (bezier.rs:105-134, 239-422, the default build), SPT_BEZIER_NEWTON = Newton's
+ * iteration from the middle of the patch inside its bounding box (bezier.rs:58-103). */
+#define SPT_BEZIER_NEWTON 1.0f
 typedef struct spt_bezier_patch {
     float cp[4][4][4];
 } spt_bezier_patch;       /* 256 B */

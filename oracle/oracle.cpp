@@ -490,9 +490,51 @@ void bezier_clipping(const Patch2& patch, V2 lu, V2 lv, float au0, float au1, fl
     }
 }
 // bezier.rs:105-134: (u, v, t) of the nearest accepted intersection
+// CubicBezier::intersect_ray of the `bezier_ni` build (bezier.rs:58-103) with Bbox::intersect_ray (bbox.rs:63-85)
+inline bool bezier_intersect_ray_newton(const spt_bezier_patch& bp, const Ray& ray, float* u_out, float* v_out, float* t_out) {
+    Vec3 lo = v3(bp.cp[0][0]), hi = lo;      // CubicBezier::new (bezier.rs:26-38)
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const Vec3 p = v3(bp.cp[i][j]);
+            lo = v3(spt_min(lo.x, p.x), spt_min(lo.y, p.y), spt_min(lo.z, p.z));
+            hi = v3(spt_max(hi.x, p.x), spt_max(hi.y, p.y), spt_max(hi.z, p.z));
+        }
+    const float x0 = (lo.x - ray.origin.x) / ray.direction.x, x1 = (hi.x - ray.origin.x) / ray.direction.x;
+    const float y0 = (lo.y - ray.origin.y) / ray.direction.y, y1 = (hi.y - ray.origin.y) / ray.direction.y;
+    const float z0 = (lo.z - ray.origin.z) / ray.direction.z, z1 = (hi.z - ray.origin.z) / ray.direction.z;
+    const float t0 = spt_max(spt_min(x0, x1), spt_max(spt_min(y0, y1), spt_min(z0, z1)));
+    const float t1 = spt_min(spt_max(x0, x1), spt_min(spt_max(y0, y1), spt_max(z0, z1)));
+    if (!(t0 <= t1)) return false;
+    float t = 0.5f * (t0 + t1), u = 0.5f, v = 0.5f;
+    for (int it = 0; it < 16; ++it) {            // NEWTON_ITERATION_MAX_TIMES
+        const Vec3 point = bezier_point_at(bp, u, v);
+        const Vec3 diff = point_at(ray, t) - point;
+        if (!spt_is_finite(t) || !spt_is_finite(u) || !spt_is_finite(v)) break;
+        if (dot(diff, diff) < 0.000000001f) {    // NEWTON_ITERATION_EPS
+            if (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f && t > ray.t_min) {
+                *u_out = u; *v_out = v; *t_out = t;
+                return true;
+            }
+            break;
+        }
+        const Vec3 dpdu = bezier_tangent_at(bp, u, v), dpdv = bezier_bitangent_at(bp, u, v);
+        const Vec3 n = cross(dpdu, dpdv);
+        float det = dot(ray.direction, n);
+        if (det == 0.0f) break;
+        det = 1.0f / det;
+        const float dt = dot(diff, n) * det;
+        const Vec3 q = cross(ray.direction, diff);
+        const float du = -dot(dpdv, q) * det;
+        const float dv = dot(dpdu, q) * det;
+        t -= dt; u -= du; v -= dv;
+    }
+    return false;
+}
+
 inline bool bezier_intersect_ray(const Ctx& cx, uint32_t bi, const Ray& ray, float* u_out, float* v_out, float* t_out) {
     cx.c->spheres++;
     const spt_bezier_patch& bp = cx.d->bezier_patches[bi];
+    if (bp.cp[0][0][3] != 0.0f) return bezier_intersect_ray_newton(bp, ray, u_out, v_out, t_out);   // SPT_BEZIER_NEWTON (ABI v12)
     Vec3 n1 = normalize(v3(-ray.direction.y, ray.direction.x, 0.0f));
     Vec3 n2 = normalize(v3(0.0f, -ray.direction.z, ray.direction.y));
     Patch2 patch;

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("SPT_LIB_DIR") or os.path.join(_HERE, "lib")   # (SPT_LIB_DIR: A/B runs against another build, tools/ only)
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 11
+SPT_ABI_VERSION = 12
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {

@@ -107,7 +107,52 @@ struct BzFrame {
 // call sites: 239 -> 173 ms on t_bezier.json against a __noinline__ call (measured).  A conservative early-out against the
 // padded box of the control points was tried and measured no gain (173.8 ms): the time goes into the clipping of the rays
 // that do reach the patch, run by a few lanes per wave, not into rays that miss its hull.
+// CubicBezier::intersect_ray of the `bezier_ni` build (bezier.rs:58-103): Newton's iteration on (t, u, v) from the middle of
+// the patch and of the ray's stretch inside the patch's bounding box (Bbox::intersect_ray, bbox.rs:63-85: IEEE divisions,
+// NaN-ignoring min / max), at most 16 steps, accepted when the ray point and the patch point are closer than sqrt(1e-9).
+constexpr uint32_t kNewtonMaxTimes = 16;
+constexpr float kNewtonEps = 0.000000001f;
+SPT_DEV bool bezier_intersect_ray_newton(const float4* cp, const DRay& ray, float* u_out, float* v_out, float* t_out) {
+    f3 lo = mk3(cp[0]), hi = lo;      // CubicBezier::new (bezier.rs:26-38): the box of the control points
+    for (int k = 1; k < 16; ++k) {
+        const f3 p = mk3(cp[k]);
+        lo = mk3(spt_min(lo.x, p.x), spt_min(lo.y, p.y), spt_min(lo.z, p.z));
+        hi = mk3(spt_max(hi.x, p.x), spt_max(hi.y, p.y), spt_max(hi.z, p.z));
+    }
+    float x0 = (lo.x - ray.o.x) / ray.d.x, x1 = (hi.x - ray.o.x) / ray.d.x;
+    float y0 = (lo.y - ray.o.y) / ray.d.y, y1 = (hi.y - ray.o.y) / ray.d.y;
+    float z0 = (lo.z - ray.o.z) / ray.d.z, z1 = (hi.z - ray.o.z) / ray.d.z;
+    const float t0 = spt_max(spt_min(x0, x1), spt_max(spt_min(y0, y1), spt_min(z0, z1)));
+    const float t1 = spt_min(spt_max(x0, x1), spt_min(spt_max(y0, y1), spt_max(z0, z1)));
+    if (!(t0 <= t1)) return false;
+    float t = 0.5f * (t0 + t1), u = 0.5f, v = 0.5f;
+    for (uint32_t it = 0; it < kNewtonMaxTimes; ++it) {
+        const f3 point = bezier_point_at(cp, u, v);
+        const f3 diff = (ray.o + ray.d * t) - point;
+        if (!spt_is_finite(t) || !spt_is_finite(u) || !spt_is_finite(v)) break;
+        if (dot(diff, diff) < kNewtonEps) {
+            if (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f && t > ray.t_min) {
+                *u_out = u; *v_out = v; *t_out = t;
+                return true;
+            }
+            break;
+        }
+        const f3 dpdu = bezier_tangent_at(cp, u, v), dpdv = bezier_bitangent_at(cp, u, v);
+        const f3 n = cross(dpdu, dpdv);
+        float det = dot(ray.d, n);
+        if (det == 0.0f) break;
+        det = 1.0f / det;
+        const float dt = dot(diff, n) * det;
+        const f3 q = cross(ray.d, diff);
+        const float du = -dot(dpdv, q) * det;
+        const float dv = dot(dpdu, q) * det;
+        t -= dt; u -= du; v -= dv;
+    }
+    return false;
+}
+
 SPT_DEV bool bezier_intersect_ray(const float4* cp_global, const DRay& ray, float* u_out, float* v_out, float* t_out) {
+    if (cp_global[0].w != 0.0f) return bezier_intersect_ray_newton(cp_global, ray, u_out, v_out, t_out);   // SPT_BEZIER_NEWTON (ABI v12)
     float4 cp[16];
     for (int k = 0; k < 16; ++k) cp[k] = cp_global[k];
     const f3 n1 = normalize(mk3(-ray.d.y, ray.d.x, 0.0f));

@@ -514,6 +514,7 @@ struct spt_scene {
     hipStream_t stream_copy = nullptr;        // SPT_RENDER_ASYNC: the film's D2H copy, next to the following render's kernels
     hipEvent_t ev_out_ready = nullptr, ev_copy_done = nullptr;
     bool copy_pending = false;                // an asynchronous copy-out of `out` may still be in flight
+    bool bez_newton = false;                  // some patch asks for Newton's iteration (the pair kernel only clips)
     // what the last pass with a counter readback saw at bounce 1 (path vertices in all shards); ~0: never seen.  A hint
     // only: it picks between two kernels that compute the same film (k_shade's kLoop)
     uint64_t tail_vertices = ~0ull;
@@ -571,6 +572,10 @@ void validate(const spt_scene_desc& s) {
     need(s.tri_attr, s.n_tris, "tri_attr");
     need(s.spheres, s.n_spheres, "spheres");
     need(s.bezier_patches, s.n_bezier_patches, "bezier_patches");
+    for (uint32_t i = 0; i < s.n_bezier_patches; ++i) {
+        const float method = s.bezier_patches[i].cp[0][0][3];
+        if (method != 0.0f && method != SPT_BEZIER_NEWTON) fail(SPT_ERR_INVALID_ARG, "scene desc: unknown Bezier intersection method (cp[0][0][3])");
+    }
     need(s.surfaces, s.n_surfaces, "surfaces");
     need(s.materials, s.n_materials, "materials");
     need(s.mediums, s.n_mediums, "mediums");
@@ -849,6 +854,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         sc->meshes.upload(s.meshes, s.n_meshes);
         sc->spheres.upload(s.spheres, s.n_spheres);
         sc->bezier.upload(s.bezier_patches, s.n_bezier_patches);
+        for (uint32_t i = 0; i < s.n_bezier_patches; ++i) sc->bez_newton = sc->bez_newton || s.bezier_patches[i].cp[0][0][3] != 0.0f;
         sc->surfaces.upload(s.surfaces, s.n_surfaces);
         sc->materials.upload(s.materials, s.n_materials);
         sc->mediums.upload(s.mediums, s.n_mediums);
@@ -1453,7 +1459,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             // SPT_BEZ_DEFER=1: the patch tests of the shadow / extension rays leave the streaming walkers for a clipping kernel
             // of their own (bezier_pairs.h).  Opt-in: bit-identical, and MEASURED slower than testing a patch where the walker
             // meets it (t_bezier.json 132 vs 130 ms, t_catmull.json 196 vs 181 ms; why: profiles/r02_experiments.md)
-            if (sc->swalk && !sc->lds_geo && sc->d.bez != nullptr && std::getenv("SPT_BEZ_DEFER") != nullptr) {
+            if (sc->swalk && !sc->lds_geo && sc->d.bez != nullptr && !sc->bez_newton && std::getenv("SPT_BEZ_DEFER") != nullptr) {
                 const size_t pairs_cap = (size_t)std::min<uint64_t>(4ull * cap, 1ull << 28);
                 for (int k = 0; k < 2; ++k) {
                     sc->bz_rec[k].ensure(pairs_cap * 48);

@@ -1722,6 +1722,10 @@ void HostScene::finalize_desc() {
     desc.n_blas_nodes = (uint32_t)blas_nodes.size(); desc.blas_nodes = blas_nodes.data();
     desc.n_tris = (uint32_t)tri_pos.size(); desc.tri_pos = tri_pos.data(); desc.tri_attr = tri_attr.data();
     desc.n_spheres = (uint32_t)spheres.size(); desc.spheres = spheres.data();
+    // SPT_BEZIER_NI=1: the reference built with `--features bezier_ni` (Cargo.toml:34-36) - every patch is intersected by
+    // Newton's iteration instead of Bezier clipping (spt_abi.h: cp[0][0][3])
+    if (const char* ni = std::getenv("SPT_BEZIER_NI"))
+        for (spt_bezier_patch& bp : bezier_patches) bp.cp[0][0][3] = (ni[0] != '\0' && ni[0] != '0') ? SPT_BEZIER_NEWTON : 0.0f;
     desc.n_bezier_patches = (uint32_t)bezier_patches.size(); desc.bezier_patches = bezier_patches.data();
     desc.n_pndfs = (uint32_t)pndfs.size(); desc.pndfs = pndfs.data();
     desc.n_pndf_terms = (uint32_t)pndf_terms.size(); desc.pndf_terms = pndf_terms.data();

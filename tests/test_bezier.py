@@ -149,3 +149,38 @@ def test_curved_patch_against_a_dense_tessellation(tmp_path):
     both = h & np.isfinite(t_tess) & well
     close = np.abs(hits["t"][both] - t_tess[both]) < 2e-2
     assert close.mean() > 0.985
+
+
+def test_newton_iteration_build_of_the_patch_test(tmp_path, monkeypatch):
+    """SPT_BEZIER_NI=1 = the reference compiled with `--features bezier_ni` (Cargo.toml:34-36, bezier.rs:58-103): Newton's
+    iteration from the middle of the patch.  Where it converges it lands ON the surface (residual < sqrt(1e-9), far tighter
+    than the clipping's tolerance), inside the unit square and in front of t_min; it finds the ONE root its start converges
+    to, so on a curved patch it reports somewhat fewer hits than the clipping, and for a ray that crosses the hill twice not
+    necessarily the nearer crossing (reference behaviour of that build)."""
+    monkeypatch.setenv("SPT_BEZIER_NI", "1")
+    sc = _scene(tmp_path, HILL, scale=[0.8, 1.2, 0.9], rotate=[0.0, 35.0, 10.0], translate=[0.3, -0.2, 0.1])
+    assert sc.array("bezier_patches")["cp"][0, 0, 0, 3] == 1.0
+    monkeypatch.delenv("SPT_BEZIER_NI")
+    clip = _scene(tmp_path, HILL, scale=[0.8, 1.2, 0.9], rotate=[0.0, 35.0, 10.0], translate=[0.3, -0.2, 0.1])
+    assert clip.array("bezier_patches")["cp"][0, 0, 0, 3] == 0.0
+    rays = _util.random_rays(sc, 3000, seed=2)
+    hn = _util.oracle_trace_closest(sc, rays)
+    hc = _util.oracle_trace_closest(clip, rays)
+    n, c = hn["instance"] >= 0, hc["instance"] >= 0
+    assert 0.1 < n.mean() <= c.mean() + 0.02
+    inst = sc.array("instances")[0]
+    cp = np.asarray(HILL, dtype=np.float64)
+    inv = inst["inv"].astype(np.float64).reshape(4, 3)
+    oo = rays["o"][n].astype(np.float64) @ inv[:3] + inv[3]
+    od = rays["d"][n].astype(np.float64) @ inv[:3]
+    p = _point_at(cp, hn["v"][n].astype(np.float64), hn["w"][n].astype(np.float64))
+    on_ray = oo + od * hn["t"][n].astype(np.float64)[:, None]
+    assert np.abs(p - on_ray).max() < 1e-4                     # |diff|^2 < 1e-9 in f32
+    assert (hn["v"][n] >= 0).all() and (hn["v"][n] <= 1).all() and (hn["w"][n] >= 0).all() and (hn["w"][n] <= 1).all()
+    assert (hn["t"][n] > rays["t_min"][n]).all()
+    both = n & c
+    same_root = np.abs(hn["t"][both] - hc["t"][both]) < 2e-2
+    assert same_root.mean() > 0.8                              # the rest: a ray that crosses the hill twice, Newton's start converged to the other crossing
+    # any-hit agrees with closest-hit on the same rays (t_max = inf)
+    occ = _util.oracle_trace_any(sc, rays)
+    assert np.array_equal(occ.astype(bool), n)

@@ -581,3 +581,42 @@ def test_large_scene_path_matches_oracle(spt, scene_name, camera, monkeypatch):
     assert l1 < L1_TOL, l1
     mism = int((got_film.view(np.uint32) != ref_film.view(np.uint32)).sum())
     assert mism == 0, "radiance not bit-exact: %d words differ, L1 %.3g" % (mism, l1)
+
+
+@pytest.mark.parametrize("scene_name,camera", [("t_bezier.json", "main"), ("t_bezier.json", "low"), ("t_catmull.json", "main")])
+def test_newton_iteration_build_of_the_patch_test_matches_oracle(spt, scene_name, camera, monkeypatch):
+    """SPT_BEZIER_NI=1 (the reference's `bezier_ni` feature, bezier.rs:58-103; ABI v12: cp[0][0][3]): Newton's iteration
+    instead of Bezier clipping, in the oracle and in every walker of libspt_hip_bez.so - rays and films bit for bit."""
+    monkeypatch.setenv("SPT_BEZIER_NI", "1")
+    sc = _scene(spt, scene_name)
+    monkeypatch.delenv("SPT_BEZIER_NI")
+    assert (sc.array("bezier_patches")["cp"][:, 0, 0, 3] == 1.0).all()
+    flags = _util.ORACLE_DEVICE if scene_name == "t_catmull.json" else _util.device_oracle_flags()
+    if scene_name != "t_catmull.json":
+        rays = _util.random_rays(sc, 100_000, seed=5)
+        ref = _util.oracle_trace_closest(sc, rays, flags)
+        got = sc.device_scene(0).trace_closest(rays)
+        assert (ref["instance"] >= 0).mean() > 0.2
+        assert ref.tobytes() == got.tobytes()
+        assert np.array_equal(_util.oracle_trace_any(sc, rays, flags), sc.device_scene(0).trace_any(rays))
+    r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RANDOM, spp=12, seed=33)
+    w, h = 160, 120
+    ref_film, _ = _util.oracle_render(sc, r, w, h, camera=camera, flags=flags)
+    for switches in ({}, {"SPT_STREAM_MASK": "0"}, {"SPT_BEZ_LDS": "1"}, {"SPT_BEZ_DEFER": "1"}):
+        for k, v in switches.items():
+            monkeypatch.setenv(k, v)
+        sc2 = _scene(spt, scene_name) if switches else sc
+        if switches:
+            monkeypatch.setenv("SPT_BEZIER_NI", "1")
+            sc2.close()
+            sc2 = _scene(spt, scene_name)
+            monkeypatch.delenv("SPT_BEZIER_NI")
+        got_film = r.render_shard(sc2, spt.OutputConfig(w, h, None, camera), samples_per_pass=5)
+        for k in switches:
+            monkeypatch.delenv(k)
+        assert np.isfinite(ref_film).all() and ref_film.max() > 0.1
+        mism = int((got_film.view(np.uint32) != ref_film.view(np.uint32)).sum())
+        assert mism == 0, "%s: %d words differ" % (switches, mism)
+        if sc2 is not sc:
+            sc2.close()
+    sc.close()

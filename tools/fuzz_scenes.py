@@ -271,10 +271,16 @@ def run_seed(seed, work):
         if os.environ.get("SPT_REFERENCE_BVH") and (any(p["type"] in ("cubic_bezier", "catmull_clark") for p in scene["primitives"])):
             switches.pop("SPT_NO_LDS_GEO", None)     # patches + the caller's trees: only the exact LDS-resident nodes follow the reference's culling
         os.environ.update(switches)
+    # FUZZ_V3: every third scene is loaded as the reference's `bezier_ni` build would see it (Newton's iteration on patches)
+    newton = bool(os.environ.get("FUZZ_V3")) and seed % 3 == 0
+    if newton:
+        os.environ["SPT_BEZIER_NI"] = "1"
     try:
         sc = spt.load_scene(path)
     except spt.SptError as e:
+        os.environ.pop("SPT_BEZIER_NI", None)
         return None, "scene rejected by the loader: %s" % str(e)[:120], path
+    os.environ.pop("SPT_BEZIER_NI", None)
     ok, words, nan_px = True, 0, 0
     # (hundreds of patch instances: the exhaustive oracle would test every ray against every patch; the tree-walking one
     #  stands in - it can lose a ray that grazes the edge of an exact box, which the comparison would show)
@@ -338,6 +344,8 @@ def run_seed(seed, work):
     info = ("%s  rays %s  %dx%d spp %d depth %d sampler %d radius %.1f shards %d/%d pass %d  inst %d lights %d env %s patches %d media %d  NaN px %d  words differ %d  %s" %
             ("ok  " if ok else "FAIL", "ok" if ray_bad == 0 else "BAD(%d)" % ray_bad, w, h, spp, r.max_depth, sampler, radius, shard_count, strip_rows, spp_pass, len(scene["instances"]), len(scene["lights"]),
              scene.get("environment", {}).get("type", "-"), sc.desc.n_bezier_patches, len(scene["mediums"]), nan_px, words, ",".join(k[:4] for k in kinds)))
+    if newton and sc.desc.n_bezier_patches:
+        info += "  newton"
     if switches:
         info += "  " + " ".join("%s=%s" % kv for kv in sorted(switches.items()))
     sc.close()
