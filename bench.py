@@ -169,7 +169,7 @@ def main():
     spt = load_pkg()
     scene = spt.load_scene(args.scene)
     # interleave granularity of the row strips: finer strips even out the ranks' shares of the object (8 ranks, slowest / mean
-    # rank on one GPU: 0.634 / 0.550 ms with 16-row strips, 0.602 / 0.571 ms with 4-row strips; tools/strip_rows_test.py)
+    # rank on one GPU: 0.634 / 0.550 ms with 16-row strips, 0.602 / 0.571 ms with 4-row strips; tools/strip_rows_sweep.py)
     strip_rows = 16 if world < 8 else 4
     scene.device_scene(local_rank)   # scene upload: outside every timed region (inputs resident in HBM)
 

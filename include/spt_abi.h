@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPT_ABI_VERSION 12
+#define SPT_ABI_VERSION 13
 
 typedef int32_t spt_status;
 enum {
@@ -364,6 +364,10 @@ enum {
                                       sum).  rgb_mean_out (page-locked, or the copy is not asynchronous) is valid after
                                       spt_render_wait or after a later synchronous spt_render on the scene returns; `stats`
                                       must be NULL (counters would need the device to be idle) */
+    ,
+    SPT_RENDER_DEBUG_NORMAL = 16u  /* ABI v13: the reference's cargo feature `debug_normal` (Cargo.toml:34-36, src/renderer/pt.rs:113-118):
+                                      a path's colour is `normal * 0.5 + 0.5` of the first surface it reaches (the world-space
+                                      interpolated normal Instance::intersect leaves in the Intersection), nothing is shaded */
 };
 
 #define SPT_N_KERNELS 7
@@ -442,6 +446,17 @@ void spt_unpin_host(void* p);
  * 2 log, 3 exp, 4 acos, 5 atan2(a,b), 6 asin, 7 round, 8 floor, 9 sqrt, 10 a/b, 11 max(a,b),
  * 12 min(a,b)), so the tests can check gfx950 returns the same bits as x86-64. */
 spt_status spt_debug_detmath(int32_t device, uint32_t fn, uint32_t n, const float* a, const float* b, float* out);
+
+/* Test seam (ABI v13) for rows a13-a16: BxdfT::{sample, bxdf, pdf} (src/bxdf/mod.rs:80-90) of ONE constant material record
+ * (`recipe` 0), evaluated on the device for n inputs in the local shading frame (z = normal).
+ *   op 0  sample: wo[3n], rng_state[n] (the PCG32 state a stream starts from, include/spt_detmath.h) ->
+ *         wi_out[3n], f_out[3n], pdf_out[n], dir_out[n] (0 reflect, 1 transmit: BxdfDirType, mod.rs:30-36)
+ *   op 1  bxdf + pdf: wo[3n], wi_in[3n] -> f_out[3n], pdf_out[n]
+ * `scene` may be NULL (then `device` says where to run) unless the record is a position-normal-distribution lobe
+ * (SPT_BXDF_PNDF_*: c1 = (1 / normalisation, sigma_p, P-NDF index as bits), ax / ay = u), whose tables live in a scene.
+ * A Subsurface substrate is refused (SPT_ERR_UNSUPPORTED): its sample places the exit point with a traced probe ray. */
+spt_status spt_debug_bxdf(const spt_scene* scene, int32_t device, const spt_material* mt, uint32_t op, uint32_t n, const float* wo,
+                          const float* wi_in, const uint64_t* rng_state, float* wi_out, float* f_out, float* pdf_out, int32_t* dir_out);
 
 const char* spt_last_error(void);
 uint32_t spt_abi_version(void);

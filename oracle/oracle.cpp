@@ -1985,7 +1985,8 @@ inline Ray shadow_ray_from_medium(const Ctx& cx, Vec3 p, Vec3 light_dir, float l
 }
 
 // PathTracer::trace_ray (pt.rs:39-210)
-Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
+// debug_normal: the reference's cargo feature of that name (Cargo.toml:34-36, pt.rs:113-118)
+Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth, bool debug_normal = false) {
     const spt_scene_desc& d = *cx.d;
     Color final_color = gray(0.0f);
     Color throughput = gray(1.0f);
@@ -2047,6 +2048,12 @@ Color trace_ray(const Ctx& cx, Ray ray, Rng& rng, uint32_t max_depth) {
             }
             break;
         } else {  // pt.rs:112-193
+            if (debug_normal) {   // pt.rs:113-118: the colour IS the normal of the first surface the path reaches
+                Color normal_color = Color{inter.normal.x, inter.normal.y, inter.normal.z};
+                normal_color = normal_color * 0.5f + gray(0.5f);
+                final_color = normal_color;
+                break;
+            }
             Vec3 po = point_at(ray, inter.t);
             const spt_instance& in = d.instances[inter.instance];
             const spt_surface& surf = d.surfaces[in.surface];
@@ -2185,7 +2192,7 @@ int oracle_render(const spt_scene_desc* desc, const spt_camera* cam, const spt_r
             ray.x_origin = rx.origin; ray.x_direction = rx.direction;
             ray.y_origin = ry.origin; ray.y_direction = ry.direction;
         }
-        return trace_ray(cx, ray, rng, p.max_depth);
+        return trace_ray(cx, ray, rng, p.max_depth, (p.flags & SPT_RENDER_DEBUG_NORMAL) != 0);
     };
     auto run_threads = [&](const std::function<void(int)>& work) {
         std::vector<std::thread> th;
@@ -2330,6 +2337,27 @@ void oracle_bxdf_eval(const spt_material* mt, const float wo[3], const float wi[
     Color f = bxdf_eval(*mt, v3(wo), v3(wi));
     bxdf_out[0] = f.r; bxdf_out[1] = f.g; bxdf_out[2] = f.b;
     *pdf_out = bxdf_pdf(*mt, v3(wo), v3(wi));
+}
+// array forms of the two seams above, the counterpart of spt_debug_bxdf (include/spt_abi.h); `d` (may be NULL) holds the
+// tables of a position-normal-distribution lobe
+void oracle_bxdf_sample_n(const spt_scene_desc* d, const spt_material* mt, uint32_t flags, uint32_t n, const float* wo, const uint64_t* rng_state,
+                          float* wi_out, float* bxdf_out, float* pdf_out, int32_t* dir_out) {
+    const Math m{(flags & ORACLE_LIBM) != 0};
+    for (uint32_t i = 0; i < n; ++i) {
+        Rng rng{{rng_state[i]}};
+        BxdfSample s = bxdf_sample(m, *mt, v3(wo + 3 * i), rng, nullptr, d);
+        wi_out[3 * i] = s.wi.x; wi_out[3 * i + 1] = s.wi.y; wi_out[3 * i + 2] = s.wi.z;
+        bxdf_out[3 * i] = s.bxdf.r; bxdf_out[3 * i + 1] = s.bxdf.g; bxdf_out[3 * i + 2] = s.bxdf.b;
+        pdf_out[i] = s.pdf;
+        dir_out[i] = s.dir;
+    }
+}
+void oracle_bxdf_eval_n(const spt_scene_desc* d, const spt_material* mt, uint32_t n, const float* wo, const float* wi, float* bxdf_out, float* pdf_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        Color f = bxdf_eval(*mt, v3(wo + 3 * i), v3(wi + 3 * i), d);
+        bxdf_out[3 * i] = f.r; bxdf_out[3 * i + 1] = f.g; bxdf_out[3 * i + 2] = f.b;
+        pdf_out[i] = bxdf_pdf(*mt, v3(wo + 3 * i), v3(wi + 3 * i), d);
+    }
 }
 void oracle_pndf_sum(const spt_scene_desc* d, uint32_t pndf, float sigma_p, uint32_t n, const float* u, float* sum_out) {
     spt_pndf_view v{d->pndfs + pndf, d->pndf_terms, d->pndf_nodes, d->pndf_refs, d->pndf_roots};

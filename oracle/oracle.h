@@ -40,6 +40,10 @@ int oracle_trace_any(const spt_scene_desc* desc, uint32_t flags, uint32_t n, con
 void oracle_bxdf_sample(const spt_material* mt, const float wo[3], uint64_t rng_state, uint32_t flags, float wi_out[3],
                         float bxdf_out[3], float* pdf_out, int32_t* dir_out);
 void oracle_bxdf_eval(const spt_material* mt, const float wo[3], const float wi[3], float bxdf_out[3], float* pdf_out);
+void oracle_bxdf_sample_n(const spt_scene_desc* d /* may be NULL */, const spt_material* mt, uint32_t flags, uint32_t n, const float* wo,
+                          const uint64_t* rng_state, float* wi_out, float* bxdf_out, float* pdf_out, int32_t* dir_out);
+void oracle_bxdf_eval_n(const spt_scene_desc* d /* may be NULL */, const spt_material* mt, uint32_t n, const float* wo, const float* wi,
+                        float* bxdf_out, float* pdf_out);
 float oracle_fresnel_dielectric(float ior, const float i[3], const float n[3]);
 float oracle_henyey_greenstein(float g, float c);
 float oracle_hg_cdf_inverse(float g, float r);

@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("SPT_LIB_DIR") or os.path.join(_HERE, "lib")   # (SPT_LIB_DIR: A/B runs against another build, tools/ only)
 REPO_ROOT = os.path.dirname(_HERE)
 
-SPT_ABI_VERSION = 12
+SPT_ABI_VERSION = 13
 SPT_LEAF_FLAG = 0x80000000
 
 STATUS_NAMES = {
@@ -180,6 +180,7 @@ RENDER_PROFILE = 1
 RENDER_BOX_RADIUS = 2
 RENDER_COUNT_VISITS = 4
 RENDER_ASYNC = 8
+RENDER_DEBUG_NORMAL = 16   # the reference's cargo feature `debug_normal` (Cargo.toml:34-36, pt.rs:113-118)
 N_KERNELS = 7
 KERNEL_NAMES = ("primary", "shade", "shadow", "extend", "resolve", "other", "shade_first")
 
@@ -273,6 +274,8 @@ def hip_lib() -> C.CDLL:
         lib.spt_unpin_host.argtypes = [C.c_void_p]
         lib.spt_unpin_host.restype = None
         lib.spt_debug_detmath.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.spt_debug_bxdf.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Material), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip_lib = lib
     return _hip_lib
 
@@ -428,7 +431,7 @@ class PathTracer:
     """reference PathTracer{max_depth, pixel_sampler, filter} (src/renderer/pt.rs:24-37)."""
 
     def __init__(self, max_depth: int = 8, sampler: int = SAMPLER_RECURRENCE, spp: int = 256,
-                 division_x: int = 0, division_y: int = 0, filter_radius: float = 0.5, seed: int = 1):
+                 division_x: int = 0, division_y: int = 0, filter_radius: float = 0.5, seed: int = 1, debug_normal: bool = False):
         self.max_depth = max_depth
         self.sampler = sampler
         self.spp = spp
@@ -436,6 +439,7 @@ class PathTracer:
         self.division_y = division_y
         self.filter_radius = filter_radius
         self.seed = seed
+        self.debug_normal = debug_normal   # a build of the reference with `--features debug_normal`: colour = normal * 0.5 + 0.5
         self.last_stats: Optional[RenderStats] = None
 
     def params(self, width: int, height: int, shard_index: int = 0, shard_count: int = 1, strip_rows: int = 16,
@@ -445,7 +449,7 @@ class PathTracer:
         p.sampler, p.division_x, p.division_y = self.sampler, self.division_x, self.division_y
         p.seed = self.seed
         p.shard_index, p.shard_count, p.strip_rows = shard_index, shard_count, strip_rows
-        p.samples_per_pass, p.flags = samples_per_pass, flags
+        p.samples_per_pass, p.flags = samples_per_pass, flags | (RENDER_DEBUG_NORMAL if self.debug_normal else 0)
         p.stats_size = C.sizeof(RenderStats)
         if self.filter_radius != 0.5:
             # BoxFilter of any radius (src/filter/boxf.rs): Film::filter_pixel sums the UNWEIGHTED colours of the
@@ -680,6 +684,32 @@ def device_detmath(fn: int, a: np.ndarray, b: Optional[np.ndarray] = None, devic
     out = np.zeros_like(a)
     _check_hip(hip_lib().spt_debug_detmath(device, fn, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
     return out
+
+
+def device_bxdf_sample(mt: "Material", wo: np.ndarray, rng_state: np.ndarray, scene: Optional[Scene] = None, device: int = 0):
+    """Test seam (spt_debug_bxdf op 0): Bxdf::sample of one constant material record on the GPU for n (wo, RNG state) pairs.
+    Returns (wi (n, 3), f (n, 3), pdf (n,), dir (n,) 0 reflect / 1 transmit)."""
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    st = np.ascontiguousarray(rng_state, dtype=np.uint64)
+    n = wo.shape[0]
+    assert st.shape == (n,)
+    wi, f, pdf, dr = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    h = scene.device_scene(device)._h if scene is not None else None
+    _check_hip(hip_lib().spt_debug_bxdf(h, device, C.byref(mt), 0, n, wo.ctypes.data, None, st.ctypes.data, wi.ctypes.data, f.ctypes.data,
+                                        pdf.ctypes.data, dr.ctypes.data))
+    return wi, f, pdf, dr
+
+
+def device_bxdf_eval(mt: "Material", wo: np.ndarray, wi: np.ndarray, scene: Optional[Scene] = None, device: int = 0):
+    """Test seam (spt_debug_bxdf op 1): Bxdf::bxdf and Bxdf::pdf on the GPU for n (wo, wi) pairs -> (f (n, 3), pdf (n,))."""
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    n = wo.shape[0]
+    assert wi.shape == (n, 3)
+    f, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    h = scene.device_scene(device)._h if scene is not None else None
+    _check_hip(hip_lib().spt_debug_bxdf(h, device, C.byref(mt), 1, n, wo.ctypes.data, wi.ctypes.data, None, None, f.ctypes.data, pdf.ctypes.data, None))
+    return f, pdf
 
 
 def device_count() -> int:

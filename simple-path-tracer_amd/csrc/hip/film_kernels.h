@@ -226,3 +226,30 @@ __global__ void k_detmath(uint32_t fn, uint32_t n, const float* a, const float* 
     }
     out[i] = r;
 }
+
+// Test seam behind spt_debug_bxdf: BxdfT::{sample, bxdf, pdf} (src/bxdf/mod.rs:80-90) of one material record, one lane per input.
+// op 0: sample(wo, rng stream) -> (wi, f, pdf, transmit); op 1: bxdf(wo, wi), pdf(wo, wi).  kScene: the record may be a
+// position-normal-distribution lobe (SPT_BXDF_PNDF_*), whose tables are read from the scene.
+template <bool kScene>
+__global__ void k_debug_bxdf(DScene sc, DMat m, uint32_t op, uint32_t n, const float* wo_in, const float* wi_in, const uint64_t* rng_state,
+                             float* wi_out, float* f_out, float* pdf_out, int32_t* dir_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 wo = mk3(wo_in[3 * i], wo_in[3 * i + 1], wo_in[3 * i + 2]);
+    if (op == 0u) {
+        DRng rng;
+        rng.s.state = rng_state[i];
+        DSubsurfaceIo io;
+        io.has = false;
+        const DBxdfSample s = mat_sample<kScene, false, false>(m, wo, rng, &sc, &io);
+        wi_out[3 * i] = s.wi.x; wi_out[3 * i + 1] = s.wi.y; wi_out[3 * i + 2] = s.wi.z;
+        f_out[3 * i] = s.f.x; f_out[3 * i + 1] = s.f.y; f_out[3 * i + 2] = s.f.z;
+        pdf_out[i] = s.pdf;
+        dir_out[i] = s.transmit ? 1 : 0;
+    } else {
+        const f3 wi = mk3(wi_in[3 * i], wi_in[3 * i + 1], wi_in[3 * i + 2]);
+        const f3 f = mat_eval<kScene>(m, wo, wi, &sc);
+        f_out[3 * i] = f.x; f_out[3 * i + 1] = f.y; f_out[3 * i + 2] = f.z;
+        pdf_out[i] = mat_pdf<kScene>(m, wo, wi, &sc);
+    }
+}

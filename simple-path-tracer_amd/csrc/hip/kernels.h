@@ -113,6 +113,7 @@ struct RenderCtx {
     uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
     BezPairs bzs, bze;                      // deferred patch tests of the shadow / extension rays (bezier_pairs.h; rec == null: off)
+    uint32_t debug_normal;                  // SPT_RENDER_DEBUG_NORMAL: the reference's `debug_normal` feature (pt.rs:113-118)
 };
 
 SPT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -616,6 +617,11 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                         if (depth != 0u) weight = power_heuristic(last_pdf, pdf_env_light(sc) * env_pdf);
                         slot_add(slot, (thr * env) * weight);
                     }
+                    alive = false;
+                } else if (rc.debug_normal != 0u) {  // pt.rs:113-118: final_color = normal * 0.5 + 0.5; break (wave-uniform branch)
+                    const f3 nc = it.normal * 0.5f + gray(0.5f);
+                    if (kFirst) first_acc = nc;        // replaces, as the reference's assignment does, whatever the path gathered before
+                    else rad_store(rc, slot, nc);
                     alive = false;
                 } else {  // pt.rs:112-193
                     const spt_surface sf = load_surface<kTab>(sc, it.surface);

@@ -501,6 +501,8 @@ struct BezierLib {
     spt_status (*render_wait)(const spt_scene*) = nullptr;
     spt_status (*trace_closest)(const spt_scene*, uint32_t, const spt_ray*, spt_hit*) = nullptr;
     spt_status (*trace_any)(const spt_scene*, uint32_t, const spt_ray*, uint8_t*) = nullptr;
+    spt_status (*debug_bxdf)(const spt_scene*, int32_t, const spt_material*, uint32_t, uint32_t, const float*, const float*, const uint64_t*, float*, float*,
+                             float*, int32_t*) = nullptr;
     const char* (*last_error)(void) = nullptr;
 };
 
@@ -765,9 +767,10 @@ const BezierLib* bezier_lib() {
         lib.render_wait = reinterpret_cast<decltype(lib.render_wait)>(dlsym(h, "spt_render_wait"));
         lib.trace_closest = reinterpret_cast<decltype(lib.trace_closest)>(dlsym(h, "spt_trace_closest"));
         lib.trace_any = reinterpret_cast<decltype(lib.trace_any)>(dlsym(h, "spt_trace_any"));
+        lib.debug_bxdf = reinterpret_cast<decltype(lib.debug_bxdf)>(dlsym(h, "spt_debug_bxdf"));
         lib.last_error = reinterpret_cast<decltype(lib.last_error)>(dlsym(h, "spt_last_error"));
         auto version = reinterpret_cast<uint32_t (*)(void)>(dlsym(h, "spt_abi_version"));
-        if (!lib.create || !lib.destroy || !lib.render || !lib.render_wait || !lib.trace_closest || !lib.trace_any || !lib.last_error || !version || version() != SPT_ABI_VERSION) {
+        if (!lib.create || !lib.destroy || !lib.render || !lib.render_wait || !lib.trace_closest || !lib.trace_any || !lib.debug_bxdf || !lib.last_error || !version || version() != SPT_ABI_VERSION) {
             err = path + " does not export ABI version " + std::to_string(SPT_ABI_VERSION);
             return;
         }
@@ -1455,6 +1458,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.stream_rounds = std::max(1u, std::min(255u, env_u32("SPT_STREAM_ROUNDS", 4u))) | (env_u32("SPT_STREAM_IFIF", 1u) ? 0x100u : 0u);
             rc.stream_refill_below = env_u32("SPT_STREAM_REFILL", 40u);
             rc.visits = sc->visits.as<unsigned long long>();
+            rc.debug_normal = (p.flags & SPT_RENDER_DEBUG_NORMAL) ? 1u : 0u;
 #if SPT_WITH_BEZIER
             // SPT_BEZ_DEFER=1: the patch tests of the shadow / extension rays leave the streaming walkers for a clipping kernel
             // of their own (bezier_pairs.h).  Opt-in: bit-identical, and MEASURED slower than testing a patch where the walker
@@ -1894,6 +1898,68 @@ spt_status spt_debug_detmath(int32_t device, uint32_t fn, uint32_t n, const floa
         return SPT_OK;
     } catch (const AbiError& e) {
         da.release(); db.release(); dout.release();
+        g_error = e.msg;
+        return e.code;
+    }
+}
+
+spt_status spt_debug_bxdf(const spt_scene* scene_c, int32_t device, const spt_material* mt, uint32_t op, uint32_t n, const float* wo,
+                          const float* wi_in, const uint64_t* rng_state, float* wi_out, float* f_out, float* pdf_out, int32_t* dir_out) {
+    if (!mt || op > 1u || (n && (!wo || !f_out || !pdf_out || (op == 0u ? (!rng_state || !wi_out || !dir_out) : !wi_in)))) {
+        g_error = "debug_bxdf: null argument or unknown op";
+        return SPT_ERR_INVALID_ARG;
+    }
+    spt_scene* sc = const_cast<spt_scene*>(scene_c);
+    if (sc && sc->fwd) {   // a patch scene lives in the other code object
+        const spt_status st = sc->fwd->debug_bxdf(sc->inner, device, mt, op, n, wo, wi_in, rng_state, wi_out, f_out, pdf_out, dir_out);
+        if (st != SPT_OK) g_error = sc->fwd->last_error();
+        return st;
+    }
+    if (n == 0) return SPT_OK;
+    DeviceBuffer dwo, dwi, drng, dwio, df, dpdf, ddir;
+    auto release = [&]() { dwo.release(); dwi.release(); drng.release(); dwio.release(); df.release(); dpdf.release(); ddir.release(); };
+    try {
+        if (mt->bxdf > SPT_BXDF_PNDF_PLASTIC) fail(SPT_ERR_INVALID_ARG, "debug_bxdf: unknown bxdf");
+        if (mt->recipe != 0u) fail(SPT_ERR_INVALID_ARG, "debug_bxdf: the record must be a constant Bxdf (recipe 0)");
+        const bool pndf = mt->bxdf == SPT_BXDF_PNDF_CONDUCTOR || mt->bxdf == SPT_BXDF_PNDF_PLASTIC;
+        if (pndf && !sc) fail(SPT_ERR_INVALID_ARG, "debug_bxdf: a position-normal-distribution lobe needs the scene that holds its tables");
+        if (pndf && (sc->pndfs.bytes == 0 || (size_t)spt_f2u(mt->c1[2]) >= sc->pndfs.bytes / sizeof(spt_pndf))) fail(SPT_ERR_INVALID_ARG, "debug_bxdf: P-NDF index (c1[2]) out of range");
+        // the exit point of a Subsurface substrate is a traced probe ray (substrate.rs:231-350): only whole films cover it
+        if (mt->substrate == SPT_SUBSTRATE_SUBSURFACE && (mt->bxdf == SPT_BXDF_MICROFACET_PLASTIC || mt->bxdf == SPT_BXDF_SPECULAR_PLASTIC || mt->bxdf == SPT_BXDF_PNDF_PLASTIC))
+            fail(SPT_ERR_UNSUPPORTED, "debug_bxdf: the Subsurface substrate samples through a probe ray and has no stand-alone seam");
+        if (sc) device = sc->device;
+        int nd = usable_device_count();
+        if (nd <= 0) fail(SPT_ERR_NO_DEVICE, "no HIP device is visible: libspt_hip has no CPU fallback");
+        if (device < 0 || device >= nd) fail(SPT_ERR_NO_DEVICE, "device index out of range");
+        HIP_CHECK(hipSetDevice(device));
+        DMat m;
+        m.bxdf = mt->bxdf;
+        m.c0 = f3{mt->c0[0], mt->c0[1], mt->c0[2]};
+        m.c1 = f3{mt->c1[0], mt->c1[1], mt->c1[2]};
+        m.c2 = f3{mt->c2[0], mt->c2[1], mt->c2[2]};
+        m.ax = mt->ax; m.ay = mt->ay; m.ior = mt->ior;
+        m.fresnel = mt->fresnel; m.substrate = mt->substrate;
+        dwo.upload(wo, (size_t)n * 3);
+        if (op == 0u) { drng.upload(rng_state, n); dwio.alloc((size_t)n * 3 * sizeof(float)); ddir.alloc((size_t)n * sizeof(int32_t)); }
+        else dwi.upload(wi_in, (size_t)n * 3);
+        df.alloc((size_t)n * 3 * sizeof(float));
+        dpdf.alloc((size_t)n * sizeof(float));
+        const dim3 grid((n + kBlock - 1) / kBlock);
+        if (pndf) hipLaunchKernelGGL(k_debug_bxdf<true>, grid, dim3(kBlock), 0, 0, sc->d, m, op, n, dwo.as<float>(), dwi.as<float>(), drng.as<uint64_t>(),
+                                     dwio.as<float>(), df.as<float>(), dpdf.as<float>(), ddir.as<int32_t>());
+        else hipLaunchKernelGGL(k_debug_bxdf<false>, grid, dim3(kBlock), 0, 0, DScene{}, m, op, n, dwo.as<float>(), dwi.as<float>(), drng.as<uint64_t>(),
+                                dwio.as<float>(), df.as<float>(), dpdf.as<float>(), ddir.as<int32_t>());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(f_out, df.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(pdf_out, dpdf.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (op == 0u) {
+            HIP_CHECK(hipMemcpy(wi_out, dwio.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(dir_out, ddir.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        release();
+        return SPT_OK;
+    } catch (const AbiError& e) {
+        release();
         g_error = e.msg;
         return e.code;
     }

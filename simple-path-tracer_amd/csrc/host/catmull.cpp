@@ -109,7 +109,7 @@ HalfEdgeMesh load_ply(const std::string& path) {
     if (!in) throw HostError(SPT_HOST_ERR_IO, "cannot open '" + path + "'");
     std::string line;
     if (!std::getline(in, line) || line.substr(0, 3) != "ply") bad(path, "not a PLY file");
-    struct Elem { std::string name; size_t count; std::vector<std::string> props; };
+    struct Elem { std::string name; size_t count = 0; std::vector<std::string> props; };
     std::vector<Elem> elems;
     bool ascii = false, header_done = false;
     while (std::getline(in, line)) {
@@ -117,7 +117,13 @@ HalfEdgeMesh load_ply(const std::string& path) {
         std::string tok;
         ls >> tok;
         if (tok == "format") { std::string fmt; ls >> fmt; ascii = fmt == "ascii"; }
-        else if (tok == "element") { Elem el; ls >> el.name >> el.count; elems.push_back(el); }
+        else if (tok == "element") {
+            Elem el;
+            double cnt = -1.0;
+            if (!(ls >> el.name >> cnt) || !(cnt >= 0.0) || cnt > 1e9 || cnt != std::floor(cnt)) bad(path, "bad element line '" + line + "'");
+            el.count = (size_t)cnt;
+            elems.push_back(el);
+        }
         else if (tok == "property" && !elems.empty()) { std::string rest; std::getline(ls, rest); elems.back().props.push_back(rest); }
         else if (tok == "end_header") { header_done = true; break; }
     }
@@ -151,17 +157,26 @@ HalfEdgeMesh load_ply(const std::string& path) {
                 auto at = [&](int c) { return (c >= 0 && (size_t)c < vals.size()) ? (float)vals[(size_t)c] : 0.0f; };
                 pos.push_back(V3{at(cx), at(cy), at(cz)});
             } else if (el.name == "face") {
-                if (vals.empty() || (size_t)vals[0] + 1 > vals.size() || vals[0] < 3) bad(path, "bad face record");
+                // the count is checked as a double BEFORE any cast: a value such as 1e30 converts to 0 on x86-64 and
+                // would pass every integer comparison (the empty face then indexed an empty vector)
+                const double cnt = vals.empty() ? -1.0 : vals[0];
+                if (!(cnt >= 3.0) || cnt != std::floor(cnt) || cnt > (double)(vals.size() - 1)) bad(path, "bad face record");
+                const size_t nfv = (size_t)cnt;
                 std::vector<int> fv;
-                for (size_t k = 0; k < (size_t)vals[0]; ++k) {
-                    const int vi = (int)vals[1 + k];
-                    if (vi < 0 || (size_t)vi >= pos.size()) bad(path, "face index out of range");
-                    fv.push_back(vi);
+                for (size_t k = 0; k < nfv; ++k) {
+                    const double dv = vals[1 + k];
+                    if (!(dv >= 0.0) || dv != std::floor(dv) || dv >= (double)pos.size()) bad(path, "face index out of range");
+                    fv.push_back((int)dv);
                 }
+                if (fv.size() < 3) bad(path, "bad face record");
                 faces.push_back(fv);
             } else if (el.name == "edge") {
                 const int c1 = col("vertex1"), c2 = col("vertex2"), cs = col("sharpness");
                 if (c1 < 0 || c2 < 0 || (size_t)std::max(c1, c2) >= vals.size()) bad(path, "bad edge record");
+                for (int c : {c1, c2}) {
+                    const double dv = vals[(size_t)c];
+                    if (!(dv >= 0.0) || dv != std::floor(dv) || dv > 2147483647.0) bad(path, "edge vertex out of range");
+                }
                 creases.push_back(Crease{(int)vals[(size_t)c1], (int)vals[(size_t)c2], (cs >= 0 && (size_t)cs < vals.size()) ? (float)vals[(size_t)cs] : 0.0f});
             }
         }

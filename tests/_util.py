@@ -74,6 +74,11 @@ def oracle_lib():
         lib.oracle_bxdf_eval.argtypes = [C.POINTER(spt.Material), C.c_float * 3, C.c_float * 3, C.c_float * 3,
                                          C.POINTER(C.c_float)]
         lib.oracle_bxdf_eval.restype = None
+        lib.oracle_bxdf_sample_n.argtypes = [C.c_void_p, C.POINTER(spt.Material), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+        lib.oracle_bxdf_sample_n.restype = None
+        lib.oracle_bxdf_eval_n.argtypes = [C.c_void_p, C.POINTER(spt.Material), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_bxdf_eval_n.restype = None
         lib.oracle_fresnel_dielectric.argtypes = [C.c_float, C.c_float * 3, C.c_float * 3]
         lib.oracle_fresnel_dielectric.restype = C.c_float
         lib.oracle_henyey_greenstein.argtypes = [C.c_float, C.c_float]
@@ -127,6 +132,28 @@ def oracle_render(scene, renderer, width, height, camera=None, flags=0, threads=
     rc = lib.oracle_render(C.byref(desc), C.byref(cam), C.byref(p), flags, threads, out.ctypes.data, C.byref(st))
     assert rc == 0
     return out, st
+
+
+def oracle_bxdf_sample_n(mt, wo, rng_state, scene=None, flags=0):
+    """Bxdf::sample for n (wo, RNG state) pairs: (wi, f, pdf, dir) arrays; `scene` holds the tables of a P-NDF lobe."""
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    st = np.ascontiguousarray(rng_state, dtype=np.uint64)
+    n = wo.shape[0]
+    wi, f, pdf, dr = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    desc = scene.desc if scene is not None else None
+    oracle_lib().oracle_bxdf_sample_n(C.byref(desc) if desc is not None else None, C.byref(mt), flags, n, wo.ctypes.data, st.ctypes.data,
+                                      wi.ctypes.data, f.ctypes.data, pdf.ctypes.data, dr.ctypes.data)
+    return wi, f, pdf, dr
+
+
+def oracle_bxdf_eval_n(mt, wo, wi, scene=None):
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    n = wo.shape[0]
+    f, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    desc = scene.desc if scene is not None else None
+    oracle_lib().oracle_bxdf_eval_n(C.byref(desc) if desc is not None else None, C.byref(mt), n, wo.ctypes.data, wi.ctypes.data, f.ctypes.data, pdf.ctypes.data)
+    return f, pdf
 
 
 def oracle_tex_eval(scene, node, uv, duvdx=(0.0, 0.0), duvdy=(0.0, 0.0), position=None, normal=None, flags=0):

@@ -225,3 +225,31 @@ def test_reference_crease_cube():
     assert len(crease) == len(smooth) == 240 and np.isfinite(crease).all()
     # creases keep the surface out at the sharp edges: it reaches farther than the smooth blob, but nowhere past the cage
     assert np.abs(smooth).max() < 0.85 and 0.9 < np.abs(crease).max() <= 1.0 + 1e-6
+
+
+PLY_HEAD = "ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+QUAD = "0 0 0\n1 0 0\n1 1 0\n0 1 0\n"
+
+
+@pytest.mark.parametrize("body,word", [
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "1e30 0 1 2 3\n", "bad face record"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "nan 0 1 2 3\n", "bad face record"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "2.5 0 1 2 3\n", "bad face record"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "2 0 1\n", "bad face record"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "4 0 1 2 1e30\n", "face index out of range"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "4 0 1 2 -1\n", "face index out of range"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "4 0 1 2 1.5\n", "face index out of range"),
+    (PLY_HEAD + "element face\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "4 0 1 2 3\n", "bad element line"),
+    (PLY_HEAD + "element\nend_header\n" + QUAD, "bad element line"),
+    (PLY_HEAD + "element face 1e30\nproperty list uchar int vertex_index\nend_header\n" + QUAD + "4 0 1 2 3\n", "bad element line"),
+    (PLY_HEAD + "element face 1\nproperty list uchar int vertex_index\nelement edge 1\nproperty int vertex1\nproperty int vertex2\n"
+     "property float sharpness\nend_header\n" + QUAD + "4 0 1 2 3\n1e30 1 2.0\n", "edge vertex out of range"),
+])
+def test_malformed_ply_records_raise_instead_of_crashing(tmp_path, body, word):
+    """a face count such as 1e30 converts to 0 on x86-64 and used to get past the integer checks (SIGSEGV on the
+    empty face).  Counts and indices are validated as doubles before any cast; a short `element` line is refused."""
+    path = tmp_path / "bad.ply"
+    path.write_text(body)
+    with pytest.raises(spt.SptError) as e:
+        spt.catmull_clark_patches(str(path), 1)
+    assert word in str(e.value), str(e.value)
