@@ -31,7 +31,7 @@ oracle:
 
 $(LIBDIR)/libspt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz -lpthread
 
 # one object per translation unit (spt_hip.hip = host side + film kernels, inst_*.hip = groups of kernel instantiations,
 # see csrc/hip/kernel_list.h), compiled side by side with `make -jN`

@@ -67,6 +67,39 @@ spt_status spt_host_read_image(const char* path, uint32_t* width, uint32_t* heig
 spt_status spt_host_catmull_clark(const char* ply_path, uint32_t fas_times, uint32_t* n_patches, float** control_points_out);
 void spt_host_free(void* p);
 
+/* ---- one call, N devices, one film -------------------------------------------------------------------------------------
+ * The reference's `render` fans the image rows out over all of its worker threads and assembles ONE film
+ * (PathTracer::render, src/renderer/pt.rs:243-287; UnsafeFilm, src/core/film.rs:101-116).  The counterpart here: one
+ * worker thread per device, each with a full scene replica (spt_scene_create on its device), device k rendering the
+ * interleaved row strips (j / strip_rows) % n == k of the image straight into the caller's film (out_strip_stride: one
+ * strided DMA per device, no host-side scatter, no collective).  Seeds depend on (pixel, sample) only, so the film is
+ * bit-identical for every n.  The device entry points arrive as a table, so that the fan-out (this library has no HIP in
+ * it) can be driven with libspt_hip.so's functions - what `spt --gpus N` and the Python binding do - or with stand-ins. */
+typedef struct spt_device_api {
+    spt_status (*scene_create)(const spt_scene_desc* desc, int32_t device, spt_scene** out);
+    void (*scene_destroy)(spt_scene* scene);
+    spt_status (*render)(const spt_scene* scene, const spt_camera* cam, const spt_render_params* params, float* rgb_mean_out,
+                         spt_render_stats* stats);
+    const char* (*last_error)(void);
+    /* optional (NULL: the film is handed to `render` as it is): page-lock / unlock the caller's film once, so that every
+     * device's copy-out is a DMA */
+    spt_status (*pin_host)(void* p, uint64_t bytes);
+    void (*unpin_host)(void* p);
+} spt_device_api;
+
+typedef struct spt_host_multi spt_host_multi;
+/* Creates one scene replica per entry of `devices` (concurrently, one thread each; an index may repeat: two workers then
+ * share that device).  Fails as a whole if any replica fails. */
+spt_status spt_host_multi_create(const spt_scene_desc* desc, const spt_device_api* api, uint32_t n_devices, const int32_t* devices,
+                                 spt_host_multi** out);
+/* Renders the full image of `params` (its shard fields are overwritten: shard k of n_devices, `strip_rows` rows per strip, 0 = a
+ * default that keeps the shares even) into film[height][width][3].  stats: NULL or n_devices entries (one per device; each
+ * is written with params->stats_size bytes as spt_render does).  Synchronous: the film is complete on return. */
+spt_status spt_host_multi_render(spt_host_multi* m, const spt_camera* cam, const spt_render_params* params, uint32_t strip_rows,
+                                 float* film, spt_render_stats* stats);
+uint32_t spt_host_multi_device_count(const spt_host_multi* m);
+void spt_host_multi_destroy(spt_host_multi* m);
+
 const char* spt_host_last_error(void);
 
 #ifdef __cplusplus

@@ -225,6 +225,12 @@ def host_lib() -> C.CDLL:
     if _host_lib is None:
         lib = _load("libspt_host.so")
         lib.spt_host_last_error.restype = C.c_char_p
+        lib.spt_host_multi_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.spt_host_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.spt_host_multi_device_count.argtypes = [C.c_void_p]
+        lib.spt_host_multi_device_count.restype = C.c_uint32
+        lib.spt_host_multi_destroy.argtypes = [C.c_void_p]
+        lib.spt_host_multi_destroy.restype = None
         lib.spt_host_load_scene.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         lib.spt_host_scene_desc.argtypes = [C.c_void_p]
         lib.spt_host_scene_desc.restype = C.POINTER(SceneDesc)
@@ -507,6 +513,62 @@ class PathTracer:
         if config.output_filename:
             write_image(config.output_filename, film)
         return film
+
+
+class DeviceApi(C.Structure):
+    """spt_device_api (include/spt_host.h): the device entry points the multi-device fan-out drives."""
+    _fields_ = [("scene_create", C.c_void_p), ("scene_destroy", C.c_void_p), ("render", C.c_void_p), ("last_error", C.c_void_p),
+                ("pin_host", C.c_void_p), ("unpin_host", C.c_void_p)]
+
+
+def hip_device_api() -> DeviceApi:
+    """The table filled with libspt_hip.so's own functions."""
+    lib = hip_lib()
+    addr = lambda f: C.cast(f, C.c_void_p).value
+    return DeviceApi(addr(lib.spt_scene_create), addr(lib.spt_scene_destroy), addr(lib.spt_render), addr(lib.spt_last_error),
+                     addr(lib.spt_pin_host), addr(lib.spt_unpin_host))
+
+
+class MultiDevice:
+    """One call, N devices, one film (spt_host_multi_*): a scene replica and a worker thread per device, interleaved row strips,
+    every device's rows DMA-ed straight into the caller's film.  The reference's counterpart is the thread fan-out of
+    PathTracer::render (src/renderer/pt.rs:243-287) into one UnsafeFilm (src/core/film.rs:101-116).
+    `api` defaults to libspt_hip.so's functions; tests pass stand-ins."""
+
+    def __init__(self, scene: Scene, devices, api: Optional[DeviceApi] = None):
+        self.scene = scene
+        self.devices = [int(d) for d in devices]
+        self._api = api if api is not None else hip_device_api()
+        self._h = C.c_void_p()
+        desc = scene.desc
+        devs = (C.c_int32 * len(self.devices))(*self.devices)
+        _check_host(host_lib().spt_host_multi_create(C.byref(desc), C.byref(self._api), len(self.devices), devs, C.byref(self._h)))
+
+    def render(self, renderer: "PathTracer", config: OutputConfig, strip_rows: int = 0, film: Optional[np.ndarray] = None,
+               samples_per_pass: int = 0) -> np.ndarray:
+        """RendererT::render over all devices: the (H, W, 3) f32 film (a caller-owned `film` is filled in place)."""
+        cam = self.scene.get_camera(config.used_camera_name)
+        p = renderer.params(config.width, config.height, 0, 1, 16, samples_per_pass)
+        if film is None:
+            film = np.zeros((config.height, config.width, 3), dtype=np.float32)
+        assert film.shape == (config.height, config.width, 3) and film.dtype == np.float32 and film.flags["C_CONTIGUOUS"]
+        stats = (RenderStats * len(self.devices))()
+        _check_host(host_lib().spt_host_multi_render(self._h, C.byref(cam), C.byref(p), strip_rows, film.ctypes.data, C.byref(stats)))
+        self.last_stats = list(stats)
+        if config.output_filename:
+            write_image(config.output_filename, film)
+        return film
+
+    def close(self) -> None:
+        if self._h:
+            host_lib().spt_host_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make_camera(eye, forward, up, fov_degrees: float) -> Camera:

@@ -113,6 +113,7 @@ struct RenderCtx {
     uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
     BezPairs bzs, bze;                      // deferred patch tests of the shadow / extension rays (bezier_pairs.h; rec == null: off)
+    const int2* row_span;                   // per image row: first / last pixel that can see an instance (null: only the rectangle above)
     uint32_t debug_normal;                  // SPT_RENDER_DEBUG_NORMAL: the reference's `debug_normal` feature (pt.rs:113-118)
 };
 
@@ -259,7 +260,11 @@ __global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI :
     // A pixel whose whole footprint lies outside the projected bounds of the scene cannot hit anything with any
     // of its samples.  Without an environment all of them are black and leave no trace (film += 0, no radiance
     // slot), so the sample loop is not entered; with one they still look the environment up, but skip the trace.
-    const bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
+    bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
+    if (in_bounds && valid && rc.row_span != nullptr) {   // the row's own span inside the rectangle (projected hulls of the instances' boxes)
+        const int2 span = rc.row_span[j];
+        in_bounds = (int32_t)i >= span.x && (int32_t)i <= span.y;
+    }
     const bool live = in_bounds || has_env;
     const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
     const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
@@ -1130,7 +1135,11 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
     uint32_t first = kChunked ? 0u : rc.pass_samples;
     const size_t plane = rc.rad_plane;
     uint32_t* hit_counter = q_count(rc.counts, 0, Q_HIT, shard);
-    const bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
+    bool in_bounds = (int32_t)i >= rc.cull_i0 && (int32_t)i <= rc.cull_i1 && (int32_t)j >= rc.cull_j0 && (int32_t)j <= rc.cull_j1;
+    if (in_bounds && valid && rc.row_span != nullptr) {   // the row's own span inside the rectangle (projected hulls of the instances' boxes)
+        const int2 span = rc.row_span[j];
+        in_bounds = (int32_t)i >= span.x && (int32_t)i <= span.y;
+    }
     const bool live = valid && (in_bounds || has_env);
     const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
     const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -535,6 +536,12 @@ struct spt_scene {
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
     bool bs_valid = false;
+    // per-row screen-space spans (spt_render): the 8 world-space corners of every instance's OBJECT-space box, the spans of
+    // the last camera / image size and their device copy
+    std::vector<std::array<double, 24>> hull_corners;
+    std::vector<int32_t> span_host;          // 2 per image row: first / last pixel that can see an instance (lo > hi: none)
+    std::vector<double> span_key;            // camera + image size the spans were made for
+    DeviceBuffer row_span;
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
     bool lds_tables = false;  // the shading tables fit LDS behind the geometry (k_shade<.., kTab>)
     bool fused = false;     // k_shade<0, ., kFused> can run: lds_tables and a simple scene
@@ -1203,6 +1210,47 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             }
             sc->bs_radius = std::sqrt(r2) * 1.001 + 1e-4;
             sc->bs_valid = finite && std::isfinite(sc->bs_radius) && sc->bs_radius < 1e18;
+            // Object-space boxes for the per-row spans: the exact bounds of a mesh's vertices / a sphere, padded a little,
+            // carried to world space by the instance matrix (a rotated cube's world AABB is far larger than its silhouette).
+            // Patches keep their (margin-widened) world box: the clipping test accepts near misses (bezier_box_margin).
+            if (sc->bs_valid && s.n_instances <= 256u) {
+                sc->hull_corners.resize(s.n_instances);
+                for (uint32_t i = 0; i < s.n_instances && !sc->hull_corners.empty(); ++i) {
+                    const spt_instance& in = s.instances[i];
+                    double olo[3] = {1e300, 1e300, 1e300}, ohi[3] = {-1e300, -1e300, -1e300};
+                    bool object_space = true;
+                    if (in.prim_type == SPT_PRIM_MESH) {
+                        const spt_mesh& m = s.meshes[in.prim_id];
+                        for (uint32_t t = m.tri_first; t < m.tri_first + m.tri_count; ++t) {
+                            const float* v[3] = {s.tri_pos[t].p0, s.tri_pos[t].p1, s.tri_pos[t].p2};
+                            for (int c = 0; c < 3; ++c)
+                                for (int k = 0; k < 3; ++k) { olo[k] = std::min(olo[k], (double)v[c][k]); ohi[k] = std::max(ohi[k], (double)v[c][k]); }
+                        }
+                        if (m.tri_count == 0) { for (int k = 0; k < 3; ++k) { olo[k] = 0; ohi[k] = 0; } }
+                    } else if (in.prim_type == SPT_PRIM_SPHERE) {
+                        const spt_sphere& sp = s.spheres[in.prim_id];
+                        for (int k = 0; k < 3; ++k) { olo[k] = (double)sp.center[k] - std::fabs((double)sp.radius); ohi[k] = (double)sp.center[k] + std::fabs((double)sp.radius); }
+                    } else {
+                        object_space = false;
+                        const double margin = bezier_box_margin(in);
+                        for (int k = 0; k < 3; ++k) { olo[k] = (double)in.bmin[k] - margin; ohi[k] = (double)in.bmax[k] + margin; }
+                    }
+                    double ext = 1e-30;
+                    for (int k = 0; k < 3; ++k) ext = std::max(ext, ohi[k] - olo[k]);
+                    bool ok = true;
+                    for (int c = 0; c < 8; ++c) {
+                        double o[3];
+                        for (int k = 0; k < 3; ++k) o[k] = ((c >> k) & 1) ? ohi[k] + 1e-4 * ext : olo[k] - 1e-4 * ext;
+                        for (int r = 0; r < 3; ++r) {
+                            double w = o[r];
+                            if (object_space) w = (double)in.fwd[r] * o[0] + (double)in.fwd[3 + r] * o[1] + (double)in.fwd[6 + r] * o[2] + (double)in.fwd[9 + r];
+                            sc->hull_corners[i][3 * c + r] = w;
+                            ok = ok && std::isfinite(w);
+                        }
+                    }
+                    if (!ok) sc->hull_corners.clear();
+                }
+            }
         }
         *out = sc;
         return SPT_OK;
@@ -1322,6 +1370,81 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         std::vector<uint32_t> h_counts;
         uint64_t seg_closest = 0, seg_shadow = 0, primary_hits = 0, path_vertices = 0, shadow_first = 0, vertices_second = 0;
         uint64_t samples_traced = 0, live_samples = 0;
+        // Per-row screen-space spans: every instance's object-space box (8 world-space corners, spt_scene_create) is
+        // projected, the convex hull of the 8 image points is the exact silhouette of the box, and row j keeps the pixels
+        // from the leftmost to the rightmost hull point within one row of slack above and below, plus one pixel each side.
+        // A pixel outside its row's span cannot see any instance with any sample (k_primary's `in_bounds`): the rotated
+        // cube of the headline scene fills 19 % of the image, its world-space AABB's rectangle 25 %.
+        const int2* row_span_dev = nullptr;
+        if (!sc->hull_corners.empty() && sc->d.env_w == 0u && std::getenv("SPT_NO_PIXEL_CULL") == nullptr && std::getenv("SPT_NO_ROW_SPANS") == nullptr) {
+            std::vector<double> key = {(double)p.width, (double)p.height, (double)cam->half_cot_half_fov};
+            for (int k = 0; k < 3; ++k) { key.push_back(cam->eye[k]); key.push_back(cam->forward[k]); key.push_back(cam->up[k]); key.push_back(cam->right[k]); }
+            if (key != sc->span_key) {
+                sc->span_key.clear();
+                std::vector<int32_t>& sp = sc->span_host;
+                sp.assign((size_t)p.height * 2, 0);
+                for (uint32_t j = 0; j < p.height; ++j) { sp[2 * j] = (int32_t)p.width; sp[2 * j + 1] = -1; }
+                const double W = (double)p.width, H = (double)p.height, aspect = W / H;
+                bool ok = true;
+                for (const auto& cn : sc->hull_corners) {
+                    double px[8], py[8];
+                    for (int c = 0; c < 8 && ok; ++c) {
+                        double z = 0, xr = 0, yu = 0, n2 = 0;
+                        for (int k = 0; k < 3; ++k) {
+                            const double v = cn[3 * c + k] - (double)cam->eye[k];
+                            z += v * (double)cam->forward[k]; xr += v * (double)cam->right[k]; yu += v * (double)cam->up[k]; n2 += v * v;
+                        }
+                        if (!(z > 1e-6 * std::sqrt(n2)) || !(z > 0)) { ok = false; break; }   // beside / behind the eye: no finite silhouette
+                        const double x = (double)cam->half_cot_half_fov * xr / z, y = (double)cam->half_cot_half_fov * yu / z;
+                        px[c] = (x / aspect + 0.5) * W;                 // pixel i covers [i, i + 1)
+                        py[c] = H - (y + 0.5) * H;                     // row j covers (j, j + 1]  (k_primary: y = ((H - j - 1) + oy) / H - 0.5)
+                        ok = std::isfinite(px[c]) && std::isfinite(py[c]) && std::fabs(px[c]) < 1e9 && std::fabs(py[c]) < 1e9;
+                    }
+                    if (!ok) break;
+                    // convex hull (monotone chain)
+                    int idx[8];
+                    for (int c = 0; c < 8; ++c) idx[c] = c;
+                    std::sort(idx, idx + 8, [&](int a, int b) { return px[a] < px[b] || (px[a] == px[b] && py[a] < py[b]); });
+                    int hull[17], hn = 0;
+                    auto crs = [&](int o, int a, int b) { return (px[a] - px[o]) * (py[b] - py[o]) - (py[a] - py[o]) * (px[b] - px[o]); };
+                    for (int c = 0; c < 8; ++c) { while (hn >= 2 && crs(hull[hn - 2], hull[hn - 1], idx[c]) <= 0) --hn; hull[hn++] = idx[c]; }
+                    for (int c = 6, lower = hn + 1; c >= 0; --c) { while (hn >= lower && crs(hull[hn - 2], hull[hn - 1], idx[c]) <= 0) --hn; hull[hn++] = idx[c]; }
+                    if (hn > 1) --hn;      // the last point repeats the first
+                    double ymin = 1e300, ymax = -1e300;
+                    for (int c = 0; c < hn; ++c) { ymin = std::min(ymin, py[hull[c]]); ymax = std::max(ymax, py[hull[c]]); }
+                    const int64_t j0 = std::max<int64_t>(0, (int64_t)std::floor(ymin) - 2), j1 = std::min<int64_t>((int64_t)p.height - 1, (int64_t)std::floor(ymax) + 2);
+                    for (int64_t j = j0; j <= j1; ++j) {
+                        const double ya = (double)j - 1.0, yb = (double)j + 2.0;    // the row's own band (j, j + 1] and one row of slack each way
+                        double xmin = 1e300, xmax = -1e300;
+                        for (int c = 0; c < hn; ++c) {
+                            const int a = hull[c], b = hull[(c + 1) % hn];
+                            double xa = px[a], yA = py[a], xb = px[b], yB = py[b];
+                            if (yA > yB) { std::swap(xa, xb); std::swap(yA, yB); }
+                            if (yB < ya || yA > yb) continue;
+                            double x0 = xa, x1 = xb;
+                            if (yB > yA) {      // clip the edge to the band
+                                const double t0 = std::max(0.0, (ya - yA) / (yB - yA)), t1 = std::min(1.0, (yb - yA) / (yB - yA));
+                                x0 = xa + (xb - xa) * t0; x1 = xa + (xb - xa) * t1;
+                            }
+                            xmin = std::min({xmin, x0, x1}); xmax = std::max({xmax, x0, x1});
+                        }
+                        if (xmin > xmax) continue;
+                        const int32_t lo = (int32_t)std::max(-1.0, std::min(W, std::floor(xmin) - 1.0)), hi = (int32_t)std::max(-1.0, std::min(W, std::floor(xmax) + 1.0));
+                        sp[2 * j] = std::min(sp[2 * j], lo);
+                        sp[2 * j + 1] = std::max(sp[2 * j + 1], hi);
+                    }
+                }
+                if (ok) {
+                    sc->row_span.ensure((size_t)p.height * 2 * sizeof(int32_t));
+                    HIP_CHECK(hipMemcpyAsync(sc->row_span.p, sp.data(), (size_t)p.height * 2 * sizeof(int32_t), hipMemcpyHostToDevice, sc->stream));
+                    HIP_CHECK(hipStreamSynchronize(sc->stream));   // `sp` is pageable; once per camera
+                    sc->span_key = key;
+                } else {
+                    sp.clear();
+                }
+            }
+            if (!sc->span_key.empty()) row_span_dev = sc->row_span.as<int2>();
+        }
         // One window of whole image rows through the wavefront pipeline.  A shard is one window (row_base 0, the
         // strip formula of the ABI); a wide box filter renders bands of consecutive rows (w_count = w_strip = 1).
         // collect: keep every sample's radiance (3 planes [c][sample][pixel] in sc->rad) instead of summing it into
@@ -1459,6 +1582,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.stream_refill_below = env_u32("SPT_STREAM_REFILL", 40u);
             rc.visits = sc->visits.as<unsigned long long>();
             rc.debug_normal = (p.flags & SPT_RENDER_DEBUG_NORMAL) ? 1u : 0u;
+            rc.row_span = row_span_dev;
 #if SPT_WITH_BEZIER
             // SPT_BEZ_DEFER=1: the patch tests of the shadow / extension rays leave the streaming walkers for a clipping kernel
             // of their own (bezier_pairs.h).  Opt-in: bit-identical, and MEASURED slower than testing a patch where the walker
@@ -1496,8 +1620,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 for (uint32_t r = 0; r < rows; ++r) {
                     const uint32_t strip = r / w_strip;
                     const int32_t j = (int32_t)(row_base + (strip * w_count + w_index) * w_strip + (r - strip * w_strip));
-                    if (j >= rc.cull_j0 && j <= rc.cull_j1)
-                        live_pixels += (uint64_t)std::max(0, std::min(rc.cull_i1, (int32_t)p.width - 1) - std::max(rc.cull_i0, 0) + 1);
+                    if (j >= rc.cull_j0 && j <= rc.cull_j1) {
+                        int32_t i0 = std::max(rc.cull_i0, 0), i1 = std::min(rc.cull_i1, (int32_t)p.width - 1);
+                        if (row_span_dev) { i0 = std::max(i0, sc->span_host[2 * (size_t)j]); i1 = std::min(i1, sc->span_host[2 * (size_t)j + 1]); }
+                        live_pixels += (uint64_t)std::max(0, i1 - i0 + 1);
+                    }
                 }
                 for (uint32_t ty = 0; ty < tiles_y; ++ty)
                     for (uint32_t tx = 0; tx < tiles_x; ++tx) {
@@ -1506,9 +1633,10 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         for (uint32_t r = ty * kTile; r < std::min(rows, (ty + 1) * kTile) && !rows_in; ++r) {
                             const uint32_t strip = r / w_strip;
                             const int32_t j = (int32_t)(row_base + (strip * w_count + w_index) * w_strip + (r - strip * w_strip));
-                            rows_in = j >= rc.cull_j0 && j <= rc.cull_j1;
+                            rows_in = j >= rc.cull_j0 && j <= rc.cull_j1 && i_hi >= rc.cull_i0 && i_lo <= rc.cull_i1;
+                            if (rows_in && row_span_dev) rows_in = i_hi >= sc->span_host[2 * (size_t)j] && i_lo <= sc->span_host[2 * (size_t)j + 1];
                         }
-                        if (rows_in && i_hi >= rc.cull_i0 && i_lo <= rc.cull_i1) ++active_tiles;
+                        if (rows_in) ++active_tiles;
                     }
             }
             HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
@@ -1660,7 +1788,11 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 }
                 if (!collect) {
                     begin(SPT_K_RESOLVE);
-                    hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
+                    // four pixels per lane when the pass was chunked (slot bits) and the planes are 16-byte aligned
+                    if (rc.slot_bits != nullptr && n_pix % 4u == 0u && std::getenv("SPT_NO_RESOLVE4") == nullptr)
+                        hipLaunchKernelGGL(k_resolve4, dim3((n_pix / 4u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc);
+                    else
+                        hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
                     end();
                 }
                 if (stats) {
