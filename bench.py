@@ -47,8 +47,59 @@ S_PATH, S_HIT, S_SHADOW, S_RAD = 72, 24, 48, 12   # S_HIT: (t, v, w, prim) + (in
 S_RAY = 32           # what a traversal reads of a path / shadow record: (origin, t_min) (direction, pdf | t_max)
 S_PATH0 = 16  # compact bounce-0 record: direction + slot
 # geometry records (SURVEY 8d / DESIGN.md section 3): node, triangle positions, triangle attributes, instance
-S_NODE, S_TRI, S_ATTR, S_INST = 64, 48, 144, 192
+# (instance: what a walker reads per instance visit - M^-1, ids, the BLAS root box and ref: 6 x 16 B, the streaming walker's
+#  96-byte record and the same six loads in trace.h's to_object + mesh root; the ABI's 192-byte spt_instance is never fetched whole)
+S_NODE, S_TRI, S_ATTR, S_INST = 64, 48, 144, 96
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Vector-ALU issue, measured on this chip (tools/issue_rate_bench*.hip -> profiles/r03_issue_rate.md): a wave64 instruction costs a
+# SIMD 2 cycles (VOP1 / VOP2 with <= 2 VGPR sources), 4 (most VOP3: three sources, compares, selects, integer multiplies, the
+# division helpers, packed f32) or 8 (transcendental unit); 1024 SIMDs at the ~2.1 GHz the chip holds under this load.
+N_SIMD = 1024
+VALU_CLOCK_GHZ = 2.1
+VALU_PEAK_VOP2_G = 950.0   # G wave-instr/s, all-VOP2 stream, measured (the guide's 2 cycles per wave64 instruction)
+
+
+def profile_json(*names):
+    """First of the committed profile summaries that exists (newest round first)."""
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(p):
+            return n, json.load(open(p))
+    return None, None
+
+
+def valu_block(kernel_class, kernel_symbol_regex, avg_launch_ms, launches_per_step, world, default_pass_layout):
+    """The instruction-issue side of the roofline for one kernel class: wave-instructions per launch from the committed PMC pass of
+    this same command, the kernel's own static instruction mix priced with the measured issue costs, and the live launch time."""
+    import re
+    vf, vj = profile_json("r03_valu_bench.json")
+    mf, mj = profile_json("r03_isa_mix.json")
+    if not vj or not avg_launch_ms or world != 1 or not default_pass_layout:
+        return None
+    e = vj["kernels"].get("k_" + kernel_class)
+    if not e or "SQ_INSTS_VALU_per_launch" not in e or (launches_per_step and e["launches"] % launches_per_step):
+        return None
+    instr = e["SQ_INSTS_VALU_per_launch"]
+    clock = VALU_CLOCK_GHZ
+    if e.get("GRBM_GUI_ACTIVE_per_launch") and e.get("SQ_BUSY_CYCLES_per_launch"):
+        pass   # (the PMC pass's own duration is not the live one; the clock constant above is the measured figure)
+    avg_cost, mix_kernel = None, None
+    if mj:
+        for name, m in mj["kernels"].items():
+            if re.search(kernel_symbol_regex, name):
+                avg_cost, mix_kernel = m["avg_issue_cycles_per_wave_instr"], name
+                break
+    achieved = instr / (avg_launch_ms * 1e-3) / 1e9
+    out = {"kernel": mix_kernel or "k_" + kernel_class, "unit": "G wave-instr/s", "wave_instr_per_launch": round(instr),
+           "lane_utilisation": round(e.get("lane_utilisation", 0.0), 4), "achieved": round(achieved, 1),
+           "peak_vop2_stream": VALU_PEAK_VOP2_G, "frac_of_vop2_stream": round(achieved / VALU_PEAK_VOP2_G, 4),
+           "source": "SQ_INSTS_VALU of profiles/%s (rocprofv3 --pmc pass of this command) / the live HIP-event launch time" % vf}
+    if avg_cost:
+        peak = N_SIMD * clock / avg_cost
+        out.update({"avg_issue_cycles_per_wave_instr": avg_cost, "peak": round(peak, 1), "frac": round(achieved / peak, 4),
+                    "peak_note": "%d SIMDs x %.1f GHz / %.2f cycles: the rate at which THIS kernel's static instruction mix (profiles/%s) "
+                                 "saturates the vector ALU" % (N_SIMD, clock, avg_cost, mf)})
+    return out
 
 
 def oracle_util():
@@ -328,7 +379,7 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected in a
         # separate rocprofv3 --pmc run of this same command and committed under profiles/ (tools/pmc_traffic.py)
         traffic, traffic_file = None, None
-        for cand in ("r02_traffic_bench.json", "r01_traffic_bench.json"):
+        for cand in ("r03_traffic_bench.json", "r02_traffic_bench.json", "r01_traffic_bench.json"):
             if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 traffic_file = cand
                 break
@@ -341,7 +392,12 @@ def main():
             "bound": "hbm", "kernel": RNAME.get(dom_name, "k_" + dom_name) + (" (bounce 0)" if dom_name == "shade_first" else ""), "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_unit": "MB per launch (PMC, profiles/%s)" % traffic_file,
             "avg_launch_ms": dom["avg_launch_ms"], "alg_MB_per_launch": dom["alg_MB_per_launch"],
+            # `bound` keeps the vocabulary of the bench contract (hbm | mfma: achieved / peak / frac above are the HBM figures of the
+            # dominant kernel); what actually limits the kernel is named here and priced in `valu`
+            "limited_by": "valu-issue",
             "limiter": "VALU instruction issue, not HBM: the scene is LDS-resident and a missing ray touches no memory at all (DESIGN.md section 6)",
+            "valu": valu_block(dom_name, {"primary": r"k_primary<true, true, false>", "shade_first": r"k_shade<0, true, true"}.get(dom_name, "k_" + dom_name),
+                               dom.get("avg_launch_ms"), dom.get("launches_per_step"), world, args.samples_per_pass == 0 and args.spp == 256),
             "kernels": kern,
             "pipeline": {"alg_bytes_per_sample": round(pipeline_bytes / max(smp, 1), 2),
                          "GBps_at_value": round(pipeline_bytes / max(smp, 1) * value * 1e6 / world / 1e9, 1)},
@@ -469,12 +525,39 @@ def other_configs(spt, device, only=""):
         else:
             entry["visits"] = None      # LDS-resident geometry: read once per workgroup, not per visit
             alg = queues
-        gbs = alg[dom] / (kms[dom] * 1e-3) / 1e9
-        entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "alg_MB": round(alg[dom] / 1e6, 1), "ms": round(kms[dom], 2),
-                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                             "note": "algorithmic bytes = queue records + visit counters x record sizes (node %d, triangle %d, instance %d B); the "
-                                     "geometry of this scene is served by L2 / Infinity Cache, so this is a fetch rate, not HBM traffic"
-                                     % (S_NODE, S_TRI, S_INST)}
+        # HBM side from the committed counters of this same workload (tools/pmc_cfg.sh: FETCH_SIZE x 2 + WRITE_SIZE per dispatch of
+        # the dominant kernel's instances) x this run's launches / this run's class time; the visit-counter figure is kept beside
+        # it as what it is: the rate at which L2 / Infinity Cache serve the walk
+        cls_kernels = {"extend": ("k_extend_stream", "k_extend_dyn", "k_extend<"), "shadow": ("k_shadow",), "primary": ("k_primary",),
+                       "shade": ("k_shade<1, false", "k_shade<2, false", "k_shade<3, false", "k_shade<0, false"),
+                       "shade_first": ("k_shade<1, true", "k_shade<2, true", "k_shade<3, true", "k_shade<0, true")}[dom]
+        tag = "cfg4" if key.startswith("cfg4") else "cfg5"
+        pf, pj = profile_json("r03_pmc_%s/pmc_summary.json" % tag)
+        hbm = None
+        if pj:
+            byt, disp = 0.0, 0
+            for kname, t in pj.items():
+                if kname.startswith(cls_kernels) and "true>" not in kname.split("(")[0][-8:] and "FETCH_SIZE" in t and t.get("dispatches"):
+                    byt += (2.0 * t["FETCH_SIZE"] + t.get("WRITE_SIZE", 0.0)) * 1024.0
+                    disp += t["dispatches"]
+            launches = int(pst.kernel_launches[list(spt.KERNEL_NAMES).index(dom)]) if dom in list(spt.KERNEL_NAMES) else 0
+            if disp and launches:
+                hbm = byt / disp * launches
+        fetch_gbs = alg[dom] / (kms[dom] * 1e-3) / 1e9
+        if hbm is not None:
+            gbs = hbm / (kms[dom] * 1e-3) / 1e9
+            entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "limited_by": "dependent-fetch latency / divergent address processing (DESIGN.md section 6)",
+                                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "hbm_MB": round(hbm / 1e6, 1), "ms": round(kms[dom], 2),
+                                 "source": "FETCH_SIZE x 2 + WRITE_SIZE per dispatch (profiles/%s) x %d launches of this run" % (pf, launches),
+                                 "cache_fetch": {"alg_MB": round(alg[dom] / 1e6, 1), "GBps": round(fetch_gbs, 1),
+                                                 "note": "queue records + visit counters x record sizes (node %d, triangle %d, instance %d B): served by L2 / "
+                                                         "Infinity Cache, NOT an HBM rate and not a roofline fraction" % (S_NODE, S_TRI, S_INST)}}
+        else:
+            entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "alg_MB": round(alg[dom] / 1e6, 1), "ms": round(kms[dom], 2),
+                                 "achieved": round(fetch_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                                 "note": "no committed counter pass for this workload: `achieved` is the L2 / Infinity-Cache fetch rate (queue records + "
+                                         "visit counters x record sizes), not HBM traffic, so no fraction of the HBM roof is claimed"}
         res[key] = entry
         sc.close()
     return res

@@ -404,12 +404,15 @@ class DeviceScene:
         return occ
 
     def close(self) -> None:
+        # an asynchronous frame may still be copying into one of the pinned film buffers: the scene goes first (its destroy
+        # drains the render and the copy stream), the buffers after it
+        if self._h:
+            hip_lib().spt_render_wait(self._h)
+            hip_lib().spt_scene_destroy(self._h)
+            self._h = C.c_void_p()
         for ptr, _ in self._pinned.values():
             hip_lib().spt_free_pinned(ptr)
         self._pinned.clear()
-        if self._h:
-            hip_lib().spt_scene_destroy(self._h)
-            self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -495,6 +498,10 @@ class PathTracer:
         if reuse_output and rows.value:
             out = ds.film_buffer(rows.value, config.width)
         else:
+            if not wait:
+                # a fresh pageable array would be the target of a copy that is still queued when this call returns, with
+                # nothing keeping it alive until wait(): the asynchronous form needs a buffer that outlives the call
+                raise SptError(1, "render_shard(wait=False) needs reuse_output=True (the scene's pinned buffer) or a caller-owned film=")
             out = np.zeros((rows.value, config.width, 3), dtype=np.float32)
         stats = RenderStats()
         _check_hip(hip_lib().spt_render(ds._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(stats) if wait else None))

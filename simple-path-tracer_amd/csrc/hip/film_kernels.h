@@ -4,6 +4,43 @@
 #include "kernels.h"
 
 // ---------------------------------------------------------------------------- resolve
+// k_resolve for passes of the chunked k_primary (slot bits; the only form the headline workload runs).
+// Only the samples marked in slot_bits own a slot; the others were black and add nothing (film.rs:87 adds +0 for them: the
+// same sum).  The additions of a pixel are sequential, so what the kernel waits for is memory latency, once per batch:
+// kBatch samples = their mask bytes + 3 kBatch slot loads are requested TOGETHER - the slot loads do not wait for the mask; an
+// unmarked slot is read (whatever it holds) and not added.  With the per-row spans nearly every live sample is marked, so the
+// extra reads are few.  (Round 2's form - mask first, then the marked slots of one byte at a time - took one round trip per 8
+// samples: 0.07 ms per launch whatever the shard size, 0.17 of the 0.6 ms step of an 8-GPU rank.)
+template <uint32_t kResolveBatch>
+__global__ void __launch_bounds__(256, 3) k_resolve_bits(RenderCtx rc) {
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= rc.n_pixels) return;
+    if (rc.first_slot[lp] >= rc.pass_samples) return;
+    const size_t plane = rc.rad_plane;
+    const float* rp = rc.rad + lp;
+    const uint8_t* bp = rc.slot_bits + lp;
+    f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
+    for (uint32_t s0 = 0; s0 < rc.pass_samples; s0 += kResolveBatch) {
+        uint32_t m = 0u;
+        float r[kResolveBatch], g[kResolveBatch], b[kResolveBatch];
+#pragma unroll
+        for (uint32_t q = 0; q < kResolveBatch / 8u; ++q)
+            if (s0 + 8u * q < rc.pass_samples) m |= (uint32_t)bp[(size_t)((s0 >> 3) + q) * rc.n_pixels] << (8u * q);
+#pragma unroll
+        for (uint32_t k = 0; k < kResolveBatch; ++k) {
+            if (s0 + k < rc.pass_samples) {
+                const size_t ri = (size_t)(s0 + k) * rc.n_pixels;
+                r[k] = rp[ri]; g[k] = rp[plane + ri]; b[k] = rp[2 * plane + ri];
+            }
+        }
+        if (m == 0u) continue;
+#pragma unroll
+        for (uint32_t k = 0; k < kResolveBatch; ++k)
+            if ((m >> k) & 1u) sum = sum + mk3(r[k], g[k], b[k]);
+    }
+    rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
+}
+
 __global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
     const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= rc.n_pixels) return;
@@ -11,34 +48,6 @@ __global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
     if (first >= rc.pass_samples) return;
     const size_t plane = rc.rad_plane;
     f3 sum = mk3(rc.film[3 * lp], rc.film[3 * lp + 1], rc.film[3 * lp + 2]);
-    if (rc.slot_bits) {
-        // chunked k_primary: only the samples marked in slot_bits own a slot; the others were black and add nothing
-        // (film.rs:87 adds +0 for them: the same sum).  Four mask bytes = 32 samples per outer iteration, the marked
-        // slots of a byte are requested together before they are added in sample order.
-        for (uint32_t s0 = 0; s0 < rc.pass_samples; s0 += 32u) {
-            uint32_t m[4];
-#pragma unroll
-            for (uint32_t g = 0; g < 4u; ++g)
-                m[g] = (s0 + 8u * g < rc.pass_samples) ? rc.slot_bits[(size_t)((s0 >> 3) + g) * rc.n_pixels + lp] : 0u;
-#pragma unroll
-            for (uint32_t g = 0; g < 4u; ++g) {
-                if (m[g] == 0u) continue;
-                float r[8], gg[8], b[8];
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; ++k) {
-                    if ((m[g] >> k) & 1u) {
-                        const size_t ri = (size_t)(s0 + 8u * g + k) * rc.n_pixels + lp;
-                        r[k] = rc.rad[ri]; gg[k] = rc.rad[plane + ri]; b[k] = rc.rad[2 * plane + ri];
-                    }
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; ++k)
-                    if ((m[g] >> k) & 1u) sum = sum + mk3(r[k], gg[k], b[k]);
-            }
-        }
-        rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
-        return;
-    }
     // the additions are sequential (sample order = the reference's, film.rs:87), the loads are not: 8 samples
     // (24 loads) in flight per lane, which matters when a narrow shard leaves few pixels to hide latency with
     uint32_t s = first;
@@ -57,57 +66,6 @@ __global__ void __launch_bounds__(256) k_resolve(RenderCtx rc) {
         sum = sum + mk3(rc.rad[ri], rc.rad[plane + ri], rc.rad[2 * plane + ri]);  // film.rs:87
     }
     rc.film[3 * lp] = sum.x; rc.film[3 * lp + 1] = sum.y; rc.film[3 * lp + 2] = sum.z;
-}
-
-// The same sum for passes of the chunked k_primary (slot bits), four neighbouring pixels per lane: every access is a
-// 16-byte load (the mask bytes of the four pixels are one dword), four samples = 12 loads in flight per lane at <= 128
-// VGPRs (4 waves / SIMD).  The one-pixel kernel above reached 3.2 TB/s at 250 VGPRs / 2 waves; a float4 stream needs the
-// width and the occupancy to approach the HBM rate (MI355X_MICROARCH.md, HBM section).  Per pixel the additions are the
-// same, in the same (sample) order.  Needs n_pixels % 4 == 0 (the host checks; the planes are then 16-byte aligned).
-__global__ void __launch_bounds__(256, 3) k_resolve4(RenderCtx rc) {
-    const uint32_t lp = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (lp >= rc.n_pixels) return;
-    const uint4 first = *reinterpret_cast<const uint4*>(rc.first_slot + lp);
-    // chunked passes: first_slot is 0 for a live pixel, pass_samples for one outside the screen-space bound, whose mask bytes
-    // were never written
-    uint32_t live = (first.x < rc.pass_samples ? 0xffu : 0u) | (first.y < rc.pass_samples ? 0xff00u : 0u) |
-                    (first.z < rc.pass_samples ? 0xff0000u : 0u) | (first.w < rc.pass_samples ? 0xff000000u : 0u);
-    if (live == 0u) return;
-    const size_t plane = rc.rad_plane;
-    float4* film4 = reinterpret_cast<float4*>(rc.film + 3u * (size_t)lp);
-    const float4 f0 = film4[0], f1 = film4[1], f2 = film4[2];      // (r0 g0 b0 r1) (g1 b1 r2 g2) (b2 r3 g3 b3)
-    float r[4] = {f0.x, f0.w, f1.z, f2.y}, g[4] = {f0.y, f1.x, f1.w, f2.z}, b[4] = {f0.z, f1.y, f2.x, f2.w};
-    for (uint32_t s0 = 0; s0 < rc.pass_samples; s0 += 8u) {
-        const uint32_t m = *reinterpret_cast<const uint32_t*>(rc.slot_bits + (size_t)(s0 >> 3) * rc.n_pixels + lp) & live;
-        if (m == 0u) continue;
-        const uint32_t any = (m | (m >> 8) | (m >> 16) | (m >> 24)) & 0xffu;   // samples some pixel of the four needs
-#pragma unroll
-        for (uint32_t h = 0; h < 8u; h += 4u) {
-            if (((any >> h) & 0xfu) == 0u) continue;
-            float4 R[4], G[4], B[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                if ((any >> (h + k)) & 1u) {
-                    const size_t ri = (size_t)(s0 + h + k) * rc.n_pixels + lp;
-                    R[k] = *reinterpret_cast<const float4*>(rc.rad + ri);
-                    G[k] = *reinterpret_cast<const float4*>(rc.rad + plane + ri);
-                    B[k] = *reinterpret_cast<const float4*>(rc.rad + 2 * plane + ri);
-                }
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                const uint32_t bit = h + k;
-                if (!((any >> bit) & 1u)) continue;
-                if ((m >> bit) & 1u) { r[0] = r[0] + R[k].x; g[0] = g[0] + G[k].x; b[0] = b[0] + B[k].x; }          // film.rs:87, sample order
-                if ((m >> (8u + bit)) & 1u) { r[1] = r[1] + R[k].y; g[1] = g[1] + G[k].y; b[1] = b[1] + B[k].y; }
-                if ((m >> (16u + bit)) & 1u) { r[2] = r[2] + R[k].z; g[2] = g[2] + G[k].z; b[2] = b[2] + B[k].z; }
-                if ((m >> (24u + bit)) & 1u) { r[3] = r[3] + R[k].w; g[3] = g[3] + G[k].w; b[3] = b[3] + B[k].w; }
-            }
-        }
-    }
-    film4[0] = make_float4(r[0], g[0], b[0], r[1]);
-    film4[1] = make_float4(g[1], b[1], r[2], g[2]);
-    film4[2] = make_float4(b[2], r[3], g[3], b[3]);
 }
 
 // film.rs:91: color / weight_sum  (Color / f32 = Color * (1/f32))

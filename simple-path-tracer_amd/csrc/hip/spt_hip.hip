@@ -684,16 +684,28 @@ void validate(const spt_scene_desc& s) {
     }
     {
         // the leaves' ranges are relative to their tree's first ref: one pass over every tree
-        std::vector<uint32_t> todo;
+        // ... and every node belongs to exactly ONE tree and is reached once (a shared child would make this walk - and a
+        // DAG-shaped descriptor the device's - exponential), at a depth the walks' fixed stacks hold: spt_pndf_calc /
+        // spt_pndf_uv_walk pop one node and push two, so an inner node at depth d (root = 1) leaves d + 1 entries pending;
+        // beyond SPT_PNDF_STACK they would drop subtrees silently (a wrong density, not an error)
+        std::vector<std::pair<uint32_t, uint32_t>> todo;
+        std::vector<uint8_t> seen(s.n_pndf_nodes, 0);
         auto check_tree = [&](uint32_t root, uint32_t first_ref) {
             if (root == 0xffffffffu) return;
             if (root >= s.n_pndf_nodes || first_ref > s.n_pndf_refs) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF tree root out of range");
-            todo.assign(1, root);
+            todo.assign(1, std::make_pair(root, 1u));
             while (!todo.empty()) {
-                const spt_pndf_node& n = s.pndf_nodes[todo.back()];
+                const uint32_t ni = todo.back().first, depth = todo.back().second;
                 todo.pop_back();
+                if (seen[ni]) fail(SPT_ERR_INVALID_ARG, "scene desc: a P-NDF node is reachable twice (trees must not share nodes)");
+                seen[ni] = 1;
+                const spt_pndf_node& n = s.pndf_nodes[ni];
                 if ((uint64_t)first_ref + n.end > s.n_pndf_refs) fail(SPT_ERR_INVALID_ARG, "scene desc: P-NDF leaf range out of bounds");
-                if (n.lc != 0xffffffffu) { todo.push_back(n.lc); todo.push_back(n.rc); }
+                if (n.lc != 0xffffffffu) {
+                    if (depth + 1u > SPT_PNDF_STACK) fail(SPT_ERR_UNSUPPORTED, "scene desc: P-NDF tree deeper than the walks' stack (" + std::to_string(SPT_PNDF_STACK) + " pending entries)");
+                    todo.emplace_back(n.lc, depth + 1u);
+                    todo.emplace_back(n.rc, depth + 1u);
+                }
             }
         };
         for (uint32_t i = 0; i < s.n_pndfs; ++i) {
@@ -1642,7 +1654,10 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             HIP_CHECK(hipMemsetAsync(rc.film, 0, (size_t)n_pix * 3 * sizeof(float), st));
             if (collect) HIP_CHECK(hipMemsetAsync(sc->rad.p, 0, (size_t)rad64 * 3 * sizeof(float), st));   // pixels outside the screen bound write no slots
             bool chunked_any = false;
-            for (uint32_t s0 = 0; s0 < p.spp; s0 += spp_pass) {
+            // max_depth 0: `while curr_depth < self.max_depth` (pt.rs:48) never runs, every sample is black - environment included.
+            // Nothing is traced: the film (and, for a wide box filter, the kept samples) stay at the zeros written above.  (The
+            // passes below would mark the hits' radiance slots as owned and no shade launch would ever write them.)
+            for (uint32_t s0 = 0; s0 < (p.max_depth == 0u ? 0u : p.spp); s0 += spp_pass) {
                 rc.pass_first = s0;
                 rc.pass_samples = std::min(spp_pass, p.spp - s0);
                 rc.rad_plane = collect ? (size_t)p.spp * n_pix : (size_t)rc.pass_samples * n_pix;
@@ -1788,11 +1803,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 }
                 if (!collect) {
                     begin(SPT_K_RESOLVE);
-                    // four pixels per lane when the pass was chunked (slot bits) and the planes are 16-byte aligned
-                    if (rc.slot_bits != nullptr && n_pix % 4u == 0u && std::getenv("SPT_NO_RESOLVE4") == nullptr)
-                        hipLaunchKernelGGL(k_resolve4, dim3((n_pix / 4u + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rc);
-                    else
-                        hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
+                    if (rc.slot_bits != nullptr && env_u32("SPT_RESOLVE_BATCH", 16u) == 32u) hipLaunchKernelGGL(k_resolve_bits<32u>, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
+                    else if (rc.slot_bits != nullptr) hipLaunchKernelGGL(k_resolve_bits<16u>, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
+                    else hipLaunchKernelGGL(k_resolve, dim3(pix_blocks), dim3(kBlock), 0, st, rc);
                     end();
                 }
                 if (stats) {

@@ -200,3 +200,48 @@ def test_async_render_delivers_the_same_film_after_wait():
     cam = sc.get_camera(None)
     assert lib.spt_render(sc.device_scene(0)._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(st)) == 1
     assert b"ASYNC" in lib.spt_last_error()
+
+
+@pytest.mark.skipif(not os.path.exists(HIP_SO), reason="libspt_hip.so not built")
+def test_pndf_trees_are_checked_for_depth_and_sharing():
+    """the device's P-NDF walks hold SPT_PNDF_STACK = 32 pending entries and used to drop subtrees silently
+    beyond that; a descriptor whose trees share a node made the validation walk exponential.  Both are refused now."""
+    lib = spt.hip_lib()
+    h = C.c_void_p()
+    sc = spt.load_scene(os.path.join(_util.SCENES, "t_pndf.json"))
+    good = sc.desc
+    nodes = sc.array("pndf_nodes")
+    node_t = nodes.dtype
+    assert good.n_pndf_nodes == len(nodes) and len(nodes) > 8
+    inner = [i for i in range(len(nodes)) if nodes["lc"][i] != 0xffffffff]
+    # (1) two parents share a child
+    shared = nodes.copy()
+    a, b = inner[0], inner[1]
+    shared["rc"][a] = shared["rc"][b] if shared["rc"][b] > a else shared["lc"][b]
+    bad = spt.SceneDesc.from_buffer_copy(good)
+    bad.pndf_nodes = C.cast(shared.ctypes.data, type(bad.pndf_nodes))
+    rc = lib.spt_scene_create(C.byref(bad), 0, C.byref(h))
+    assert rc == 1 and b"reachable twice" in lib.spt_last_error(), lib.spt_last_error()
+    # (2) a chain of 40 inner nodes (each with a leaf as its left child) appended behind the table, hung below a leaf-turned-inner
+    import numpy as np
+    n0 = len(nodes)
+    leaf = next(i for i in range(n0) if nodes["lc"][i] == 0xffffffff)
+    chain = np.zeros(2 * 40 + 1, dtype=node_t)
+    chain[:] = nodes[leaf]                       # boxes / ranges of a valid leaf
+    # node `leaf` -> (n0, n0 + 1); inner n0 + 1 -> (n0 + 2, n0 + 3); ...
+    deep = np.concatenate([nodes, chain])
+    cur = leaf
+    for k in range(40):
+        deep["lc"][cur] = n0 + 2 * k
+        deep["rc"][cur] = n0 + 2 * k + 1
+        cur = n0 + 2 * k + 1
+    bad = spt.SceneDesc.from_buffer_copy(good)
+    bad.pndf_nodes = C.cast(deep.ctypes.data, type(bad.pndf_nodes))
+    bad.n_pndf_nodes = len(deep)
+    rc = lib.spt_scene_create(C.byref(bad), 0, C.byref(h))
+    assert rc == 4 and b"deeper than the walks' stack" in lib.spt_last_error(), lib.spt_last_error()
+    # the untouched descriptor passes validation (and then fails only for want of a device, here)
+    rc = lib.spt_scene_create(C.byref(good), 0, C.byref(h))
+    assert rc in (0, 2)
+    if rc == 0:
+        lib.spt_scene_destroy(h)

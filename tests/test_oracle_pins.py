@@ -237,3 +237,60 @@ def test_tie_rule_is_order_independent(tmp_path):
     # on the shared diagonal both triangles of the quad tie as well: the lower prim index wins
     diag = _rays([[0.3, 0.3, 3.0]], [[0.0, 0.0, -1.0]])
     assert _util.oracle_trace_closest(sc, diag, _util.ORACLE_TIE_MIN_ID)["prim"][0] == 0
+
+
+# ---------------------------------------------------------------- the headline workload's mesh
+REF_CUBE = "/root/reference/scenes/models/cube.obj"
+
+
+def _obj_triangles(path):
+    """{triangle} of an OBJ file, each a frozenset of its three (position, normal) corners: what the integrator can see of a
+    mesh whose material ignores texcoords (vertex order, face order and index sharing do not matter)."""
+    v, vn, tris = [], [], set()
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            v.append(tuple(float(x) for x in t[1:4]))
+        elif t[0] == "vn":
+            vn.append(tuple(float(x) for x in t[1:4]))
+        elif t[0] == "f":
+            c = []
+            for w in t[1:]:
+                idx = w.split("/")
+                c.append((v[int(idx[0]) - 1], vn[int(idx[2]) - 1]))
+            for k in range(1, len(c) - 1):
+                tris.add(frozenset((c[0], c[k], c[k + 1])))
+    return tris
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CUBE), reason="the reference's model files are only present in the build container")
+def test_generated_cube_is_the_reference_cube(tmp_path):
+    """scenes_amd/models/cube.obj is generated (24 vertices, another face / uv order) because reference files are not copied
+    into the repo; the headline workload claims to be the reference's scenes/test_scene_01.json.  Read in place as data:
+    the two files describe the same 12 triangles with the same normals, and the scene rendered from the reference's own
+    file has the same closed-form film (interior pixels to 1e-5; the two visible face radiances 0.3363 / 1.2552)."""
+    ours = _obj_triangles(os.path.join(_util.SCENES, "models", "cube.obj"))
+    theirs = _obj_triangles(REF_CUBE)
+    assert len(ours) == len(theirs) == 12 and ours == theirs
+    scene = json.load(open(os.path.join(_util.SCENES, "cfg2_cube.json")))
+    n_prims = 0
+    for prim in (scene["primitives"] if isinstance(scene["primitives"], list) else [scene["primitives"]]):
+        if prim.get("obj_file"):
+            prim["obj_file"] = os.path.relpath(REF_CUBE, str(tmp_path))     # (the loader resolves model files against the scene file)
+            n_prims += 1
+    assert n_prims == 1
+    p = tmp_path / "scene_01_with_reference_cube.json"
+    p.write_text(json.dumps(scene))
+    r = spt.PathTracer(max_depth=8, spp=4, seed=1)
+    a, _ = _util.oracle_render(_scene("cfg2_cube.json"), r, 192, 192)
+    b, _ = _util.oracle_render(spt.load_scene(str(p)), r, 192, 192)
+    lum = (5.0 / np.pi * np.array([np.sin(np.radians(60.0)) + np.cos(np.radians(60.0)), np.sin(np.radians(60.0)) - np.cos(np.radians(60.0))]) / np.sqrt(3.0))
+    for film in (a, b):
+        g = film[..., 0]
+        interior = (np.abs(g) < 2e-5) | (np.abs(g - lum[0]) < 2e-5) | (np.abs(g - lum[1]) < 2e-5)
+        assert interior.mean() > 0.96 and abs((g > 0.01).mean() - 0.1846) < 0.012
+    same = np.abs(a - b) < 1e-5
+    assert same.mean() > 0.995      # silhouette / edge samples can fall either side in the last bit: another vertex order rounds differently
+    assert np.abs(a - b).mean() < 1e-4

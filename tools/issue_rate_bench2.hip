@@ -16,11 +16,11 @@ static constexpr int kTrips = 2048;   // 32 measured instructions per trip
 // eight destination registers, 4 rounds = 32 instructions
 #define BODY8(M, r0, r1, r2, r3, r4, r5, r6, r7) X4(M(r0) M(r1) M(r2) M(r3) M(r4) M(r5) M(r6) M(r7))
 #define CLOB "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", \
-             "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "s20", "s21", "s22", "scc", "vcc"
+             "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "s20", "s21", "s22", "s24", "s25", "scc", "vcc"
 #define PRO "v_mov_b32 v4, %1\n v_mov_b32 v5, %2\n v_mov_b32 v40, %2\n v_mov_b32 v41, %1\n s_mov_b32 s21, 0x3f7fbe77\n s_mov_b32 s22, 0x38d1b717\n" \
             "v_mov_b32 v8, %0\n v_mov_b32 v9, %0\n v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n v_mov_b32 v14, %0\n v_mov_b32 v15, %0\n" \
             "v_mov_b32 v16, %0\n v_mov_b32 v18, %0\n v_mov_b32 v19, %0\n v_mov_b32 v20, %0\n v_mov_b32 v22, %0\n v_mov_b32 v23, %0\n v_mov_b32 v24, %0\n v_mov_b32 v28, %0\n" \
-            "v_mov_b32 v32, %0\n v_mov_b32 v36, %0\n s_mov_b32 s20, %3\n 1:\n"
+            "v_mov_b32 v32, %0\n v_mov_b32 v36, %0\n v_cmp_lt_f32 vcc, v4, v5\n v_cmp_lt_f32 s[24:25], v5, v4\n s_nop 4\n s_mov_b32 s20, %3\n 1:\n"
 #define EPI "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n" \
             "v_add_f32 %0, v8, v9\n v_add_f32 %0, %0, v10\n v_add_f32 %0, %0, v11\n v_add_f32 %0, %0, v12\n v_add_f32 %0, %0, v16\n v_add_f32 %0, %0, v20\n"
 
@@ -36,6 +36,9 @@ static constexpr int kTrips = 2048;   // 32 measured instructions per trip
 #define M_MAX3(d) I3("v_max3_f32", d, 4, 5)
 #define M_CNDMASK(d) "v_cndmask_b32 v" #d ", v" #d ", v4, vcc\n"
 #define M_CMP(d) "v_cmp_lt_f32 vcc, v" #d ", v4\n"
+#define M_CNDMASK_SGPR(d) "v_cndmask_b32_e64 v" #d ", v" #d ", v4, s[24:25]\n"          // mask in an SGPR pair written once before the loop
+#define M_CMP_CNDMASK(d) "v_cmp_lt_f32 vcc, v" #d ", v4\n v_cndmask_b32 v" #d ", v" #d ", v5, vcc\n"   // the pair real code issues (counted as 2)
+#define M_CMP_SGPR(d) "v_cmp_lt_f32 s[24:25], v" #d ", v4\n"
 #define M_MULHI(d) I2("v_mul_hi_u32", d, 4)
 #define M_MAD64(d) "v_mad_u64_u32 v[" #d ":" #d "+1], vcc, v4, v5, v[" #d ":" #d "+1]\n"
 #define M_LSHL(d) "v_lshlrev_b32 v" #d ", 1, v" #d "\n"
@@ -46,14 +49,15 @@ static constexpr int kTrips = 2048;   // 32 measured instructions per trip
 #define M_DIVFMAS(d) "v_div_fmas_f32 v" #d ", v" #d ", v4, v5\n"
 
 enum { V_FMA_ROT = 0, V_FMA_NOCONFLICT, V_FMA_SAMEBANK, V_FMAC, V_FMAAK, V_FMA_SGPR, V_FMA_2SAME, V_MUL, V_ADD, V_MULADD, V_MAX3, V_CNDMASK, V_CMP, V_MULHI,
-       V_MAD64, V_LSHL, V_AND, V_ADD3, V_DIVSCALE, V_DIVFIXUP, V_DIVFMAS, V_LDS_CHASE, N_VAR };
+       V_MAD64, V_LSHL, V_AND, V_ADD3, V_DIVSCALE, V_DIVFIXUP, V_DIVFMAS, V_LDS_CHASE, V_CNDMASK_SGPR, V_CMP_CNDMASK, V_CMP_SGPR, N_VAR };
 static const char* var_name[N_VAR] = {
     "v_fma_f32 d,d,m,c  (d over banks 0-3, m bank 0, c bank 1)", "v_fma_f32 d,d,m,c  (d in banks 2/3 only: no two sources share a bank)",
     "v_fma_f32 d,d,m,c  (all three sources in bank 0)", "v_fmac_f32 d,m,c", "v_fmaak_f32 d,d,m,literal", "v_fma_f32 d,d,SGPR,c", "v_fma_f32 d,d,m,m",
     "v_mul_f32 d,d,m", "v_add_f32 d,d,c", "v_mul_f32 + v_add_f32 (a*b+c with contraction off; counted as 2)", "v_max3_f32 d,d,m,c", "v_cndmask_b32 d,d,m,vcc",
     "v_cmp_lt_f32 vcc,d,m", "v_mul_hi_u32 d,d,m", "v_mad_u64_u32", "v_lshlrev_b32 d,1,d", "v_and_b32 d,d,m", "v_add3_u32 d,d,m,c", "v_div_scale_f32", "v_div_fixup_f32",
-    "v_div_fmas_f32", "ds_read_b32 dependent chain (LDS pointer chase; latency)"};
-static const int var_instr_per_trip[N_VAR] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};
+    "v_div_fmas_f32", "ds_read_b32 dependent chain (LDS pointer chase; latency)", "v_cndmask_b32_e64 d,d,m,s[24:25] (mask written once)",
+    "v_cmp_lt_f32 vcc + v_cndmask_b32 vcc pairs (counted as 2)", "v_cmp_lt_f32 s[24:25],d,m (VOP3 compare into an SGPR pair)"};
+static const int var_instr_per_trip[N_VAR] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32};
 
 template <int V>
 __global__ void __launch_bounds__(256) k_var(float* out, unsigned long long* cycles, float seed) {
@@ -84,6 +88,9 @@ __global__ void __launch_bounds__(256) k_var(float* out, unsigned long long* cyc
     else if constexpr (V == V_DIVSCALE) asm volatile(PRO BODY8(M_DIVSCALE, 10, 11, 14, 15, 18, 19, 22, 23) EPI : "+v"(x) : "v"(m), "v"(c), "n"(kTrips) : CLOB);
     else if constexpr (V == V_DIVFIXUP) asm volatile(PRO BODY8(M_DIVFIXUP, 10, 11, 14, 15, 18, 19, 22, 23) EPI : "+v"(x) : "v"(m), "v"(c), "n"(kTrips) : CLOB);
     else if constexpr (V == V_DIVFMAS) asm volatile(PRO BODY8(M_DIVFMAS, 10, 11, 14, 15, 18, 19, 22, 23) EPI : "+v"(x) : "v"(m), "v"(c), "n"(kTrips) : CLOB);
+    else if constexpr (V == V_CNDMASK_SGPR) asm volatile(PRO BODY8(M_CNDMASK_SGPR, 10, 11, 14, 15, 18, 19, 22, 23) EPI : "+v"(x) : "v"(m), "v"(c), "n"(kTrips) : CLOB);
+    else if constexpr (V == V_CMP_CNDMASK) asm volatile(PRO BODY8(M_CMP_CNDMASK, 10, 11, 14, 15, 18, 19, 22, 23) EPI : "+v"(x) : "v"(m), "v"(c), "n"(kTrips) : CLOB);
+    else if constexpr (V == V_CMP_SGPR) asm volatile(PRO BODY8(M_CMP_SGPR, 10, 11, 14, 15, 18, 19, 22, 23) EPI : "+v"(x) : "v"(m), "v"(c), "n"(kTrips) : CLOB);
     else if constexpr (V == V_LDS_CHASE) {
         unsigned p = (threadIdx.x & 1023u) * 4u;
         for (int it = 0; it < kTrips; ++it) {

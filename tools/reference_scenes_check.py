@@ -74,8 +74,18 @@ def run():
             continue
         r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RANDOM, spp=8, seed=5)
         w, h = 160, 120
-        ref, _ = _util.oracle_render(sc, r, w, h, flags=_util.device_oracle_flags())
+        flags = _util.device_oracle_flags()
+        if sc.desc.n_instances > 100:
+            # the Catmull-Clark scenes (19 / 20: ~1 000 / ~250 patch instances): the exhaustive oracle clips EVERY patch for every
+            # ray segment (hours of host time even for a thumbnail), so these two are compared in the other pairing - the
+            # caller's trees on both sides (SPT_REFERENCE_BVH=1 vs the tree-walking oracle) - on a smaller image
+            os.environ["SPT_REFERENCE_BVH"] = "1"
+            flags = _util.ORACLE_DEVICE
+            r.spp, w, h = 4, 96, 72
+        print(name, "...", flush=True)
+        ref, _ = _util.oracle_render(sc, r, w, h, flags=flags)
         got = r.render_shard(sc, spt.OutputConfig(w, h))
+        os.environ.pop("SPT_REFERENCE_BVH", None)
         nan = np.isnan(ref)
         diff = int((got.view(np.uint32) != ref.view(np.uint32))[~nan].sum())
         print(name, "instances", sc.desc.n_instances, "triangles", sc.desc.n_tris, "mean %.4f" % float(np.nanmean(ref)),

@@ -13,7 +13,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 240 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --steps 1 --warmup 0 --profile-steps 0 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1 || { echo pmc $c failed; tail -5 $O/pmc_$c.log; exit 1; }
 done
-timeout -k 10 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -- python bench.py --steps 1 --warmup 0 --profile-steps 0 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1 || { echo pmc sq failed; tail -5 $O/pmc_sq.log; }
+timeout -k 10 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python bench.py --steps 1 --warmup 0 --profile-steps 0 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1 || { echo pmc sq failed; tail -5 $O/pmc_sq.log; }
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --single-device --no-cpu-baseline --no-secondary --profile-steps 0 > $O/bench_2rank_one_gpu.json 2> $O/bench_2rank.err || { echo 2rank failed; tail -8 $O/bench_2rank.err; }
 echo "2rank: $(tail -1 $O/bench_2rank_one_gpu.json | cut -c1-200)"
 find $O -name "*.csv" | head -20
