@@ -38,6 +38,11 @@ const spt_scene_desc* spt_host_scene_desc(const spt_host_scene* scene);
 /* name == NULL: the scene must have exactly one camera (reference panics otherwise). */
 spt_status spt_host_scene_camera(const spt_host_scene* scene, const char* name, spt_camera* out);
 void spt_host_scene_free(spt_host_scene* scene);
+/* Which routine intersects the scene's Bezier patches (Catmull-Clark surfaces included): 0 = Bezier clipping, the reference's
+ * default build; 1 = Newton's iteration, the reference built with `--features bezier_ni` (Cargo.toml:34-36, bezier.rs:58-103).
+ * Sets spt_bezier_patch::cp[0][0][3] of every patch of THIS scene (call it before spt_scene_create); without the call the
+ * process-wide default applies (clipping, or Newton when the environment variable SPT_BEZIER_NI is set to a non-zero value). */
+spt_status spt_host_scene_set_bezier_newton(spt_host_scene* scene, int32_t newton);
 
 /* Fills max_depth, spp, sampler, division_x/y of *params (other fields untouched)
  * and the box-filter radius. */

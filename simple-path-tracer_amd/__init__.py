@@ -225,6 +225,7 @@ def host_lib() -> C.CDLL:
     if _host_lib is None:
         lib = _load("libspt_host.so")
         lib.spt_host_last_error.restype = C.c_char_p
+        lib.spt_host_scene_set_bezier_newton.argtypes = [C.c_void_p, C.c_int32]
         lib.spt_host_multi_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
         lib.spt_host_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.spt_host_multi_device_count.argtypes = [C.c_void_p]
@@ -364,9 +365,14 @@ class Scene:
             pass
 
 
-def load_scene(path: str) -> Scene:
-    """loader::load_scene (src/loader/mod.rs:20-31)."""
-    return Scene(path)
+def load_scene(path: str, bezier_newton: Optional[bool] = None) -> Scene:
+    """loader::load_scene (src/loader/mod.rs:20-31).  bezier_newton: True = the reference built with `--features bezier_ni`
+    (patches intersected by Newton's iteration), False = Bezier clipping, None = the process default (clipping unless the
+    environment variable SPT_BEZIER_NI is set).  Per scene: two scenes of one process may differ."""
+    sc = Scene(path)
+    if bezier_newton is not None:
+        _check_host(host_lib().spt_host_scene_set_bezier_newton(sc._h, 1 if bezier_newton else 0))
+    return sc
 
 
 class DeviceScene:

@@ -2,7 +2,7 @@
 //   spt -s scene.json -r renderer.json [-w 512] [-h 512] -o out.png [-c camera]
 // plus --seed, --spp, --device D | --gpus N (one image over N devices: one worker thread and one scene replica per device,
 // interleaved row strips, one film - spt_host_multi_*, the counterpart of the thread fan-out of pt.rs:243-287),
-// --strip-rows R and --debug-normal (the reference's cargo feature of that name, pt.rs:113-118).  It loads the scene
+// --strip-rows R, --debug-normal and --bezier-ni (the reference's two cargo features, Cargo.toml:34-36: pt.rs:113-118, bezier.rs:58-103).  It loads the scene
 // with libspt_host, renders with libspt_hip (HIP kernels only) and writes the image; like the reference it reports the
 // time spent inside `render`.
 #include <algorithm>
@@ -18,7 +18,7 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: spt -s <scene.json> -r <renderer.json> -o <out.png> [-w 512] [-h 512] [-c camera]\n"
-                 "           [--seed N] [--spp N] [--device D | --gpus N | --devices a,b,..] [--strip-rows R] [--debug-normal]\n");
+                 "           [--seed N] [--spp N] [--device D | --gpus N | --devices a,b,..] [--strip-rows R] [--debug-normal] [--bezier-ni]\n");
 }
 
 int main(int argc, char** argv) {
@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 1;
     int device = 0, gpus = 0;
     uint32_t strip_rows = 0;
-    bool debug_normal = false;
+    bool debug_normal = false, bezier_ni = false;
     std::vector<int32_t> device_list;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
         }
         else if (a == "--strip-rows") strip_rows = (uint32_t)std::atoi(next());
         else if (a == "--debug-normal") debug_normal = true;
+        else if (a == "--bezier-ni") bezier_ni = true;
         else { usage(); return 2; }
     }
     if (scene_path.empty() || renderer_path.empty() || out_path.empty()) { usage(); return 2; }
@@ -71,6 +72,7 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "Error: %s\n", spt_host_last_error());
         return 1;
     }
+    if (bezier_ni) spt_host_scene_set_bezier_newton(hs, 1);   // `cargo build --features bezier_ni`
     spt_render_params params;
     std::memset(&params, 0, sizeof params);
     float radius = 0.5f;

@@ -183,8 +183,7 @@ __global__ void __launch_bounds__(256) k_trace_closest_stream(DScene sc, uint32_
         r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
         wk.begin(sc, r, rays[i].t_max);
     }
-    BezDefer no_defer{nullptr, nullptr, 0u, 0u, 0u};   // the ray seams test every patch where they meet it
-    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem, no_defer);
+    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem);
     if (i >= n) return;
     const bool hit = wk.h.inst >= 0;
     hits[i].t = hit ? wk.h.t : SPT_F32_MAX;
@@ -204,8 +203,7 @@ __global__ void __launch_bounds__(256) k_trace_any_stream(DScene sc, uint32_t n,
         r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
         wk.begin(sc, r, rays[i].t_max);
     }
-    BezDefer no_defer{nullptr, nullptr, 0u, 0u, 0u};   // the ray seams test every patch where they meet it
-    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem, no_defer);
+    for (uint32_t guard = 0; guard < (1u << 20) && __ballot(!wk.done) != 0ull; ++guard) wk.run(sc, 8u, spill_mem);
     if (i < n) occluded[i] = wk.h.inst >= 0 ? 1 : 0;
 }
 
@@ -250,7 +248,7 @@ __global__ void k_debug_bxdf(DScene sc, DMat m, uint32_t op, uint32_t n, const f
         rng.s.state = rng_state[i];
         DSubsurfaceIo io;
         io.has = false;
-        const DBxdfSample s = mat_sample<kScene, false, false>(m, wo, rng, &sc, &io);
+        const DBxdfSample s = mat_sample<false, false, false, kScene>(m, wo, rng, &sc, &io);
         wi_out[3 * i] = s.wi.x; wi_out[3 * i + 1] = s.wi.y; wi_out[3 * i + 2] = s.wi.z;
         f_out[3 * i] = s.f.x; f_out[3 * i + 1] = s.f.y; f_out[3 * i + 2] = s.f.z;
         pdf_out[i] = s.pdf;

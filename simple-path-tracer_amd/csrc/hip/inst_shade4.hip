@@ -1,3 +1,3 @@
 // one group of kernel instantiations (see kernel_list.h)
-#define SPT_INSTANTIATE_GROUP_WST 1
+#define SPT_INSTANTIATE_GROUP_SHADE4 1
 #include "kernel_list.h"

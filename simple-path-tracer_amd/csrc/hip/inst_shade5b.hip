@@ -1,0 +1,3 @@
+// one group of kernel instantiations (see kernel_list.h)
+#define SPT_INSTANTIATE_GROUP_SHADE5B 1
+#include "kernel_list.h"

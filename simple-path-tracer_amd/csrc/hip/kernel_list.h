@@ -73,35 +73,28 @@
     X((k_shade<3, true, false, false, true>), SPT_ARGS_BOUNCE)       \
     X((k_shade<3, false, false, false, true>), SPT_ARGS_BOUNCE)
 
-// kind-sorted traversal (wst.h): k_trace_wst<Policy, kCount>
-#define SPT_ARGS_WST (DScene, RenderCtx, uint32_t, uint2*)
-#define SPT_KERNELS_WST(X)                              \
-    X((k_trace_wst<WstExtend, false>), SPT_ARGS_WST)    \
-    X((k_trace_wst<WstExtend, true>), SPT_ARGS_WST)     \
-    X((k_trace_wst<WstShadow, false>), SPT_ARGS_WST)    \
-    X((k_trace_wst<WstShadow, true>), SPT_ARGS_WST)
-
-// deferred patch tests (bezier_pairs.h)
-#if SPT_WITH_BEZIER
-#define SPT_KERNELS_BEZ(X)                                                            \
-    X((k_bezier_pairs<false>), (DScene, BezPairs))                                    \
-    X((k_bezier_pairs<true>), (DScene, BezPairs))                                     \
-    X((k_bezier_commit<0>), (BezPairs))                                               \
-    X((k_bezier_finish_shadow<0>), (RenderCtx, BezPairs))                             \
-    X((k_bezier_finish_extend<0>), (DScene, RenderCtx, BezPairs, uint32_t))
-#else
-#define SPT_KERNELS_BEZ(X)
-#endif
+// k_shade<4, .>: position-normal distributions without a BSSRDF probe (kGeoLds plays no role: two table variants)
+#define SPT_KERNELS_SHADE4(X)                                        \
+    X((k_shade<4, true, false, true, true>), SPT_ARGS_BOUNCE)        \
+    X((k_shade<4, false, false, true, true>), SPT_ARGS_BOUNCE)       \
+    X((k_shade<4, true, false, false, false>), SPT_ARGS_BOUNCE)      \
+    X((k_shade<4, false, false, false, false>), SPT_ARGS_BOUNCE)
+// k_shade<5, .>: both
+#define SPT_KERNELS_SHADE5A(X)                                       \
+    X((k_shade<5, true, false, true, true>), SPT_ARGS_BOUNCE)        \
+    X((k_shade<5, false, false, true, true>), SPT_ARGS_BOUNCE)       \
+    X((k_shade<5, true, false, false, false>), SPT_ARGS_BOUNCE)
+#define SPT_KERNELS_SHADE5B(X)                                       \
+    X((k_shade<5, false, false, false, false>), SPT_ARGS_BOUNCE)     \
+    X((k_shade<5, true, false, false, true>), SPT_ARGS_BOUNCE)       \
+    X((k_shade<5, false, false, false, true>), SPT_ARGS_BOUNCE)
 
 #if defined(SPT_INSTANTIATE_GROUP_PRIMARY)
 SPT_KERNELS_PRIMARY(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_RAYS)
 SPT_KERNELS_RAYS(SPT_DEFINE_KERNEL)
-#elif defined(SPT_INSTANTIATE_GROUP_WST)
-SPT_KERNELS_WST(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_STREAM)
 SPT_KERNELS_STREAM(SPT_DEFINE_KERNEL)
-SPT_KERNELS_BEZ(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE0)
 SPT_KERNELS_SHADE0(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE1)
@@ -112,15 +105,22 @@ SPT_KERNELS_SHADE2(SPT_DEFINE_KERNEL)
 SPT_KERNELS_SHADE3A(SPT_DEFINE_KERNEL)
 #elif defined(SPT_INSTANTIATE_GROUP_SHADE3B)
 SPT_KERNELS_SHADE3B(SPT_DEFINE_KERNEL)
+#elif defined(SPT_INSTANTIATE_GROUP_SHADE4)
+SPT_KERNELS_SHADE4(SPT_DEFINE_KERNEL)
+#elif defined(SPT_INSTANTIATE_GROUP_SHADE5A)
+SPT_KERNELS_SHADE5A(SPT_DEFINE_KERNEL)
+#elif defined(SPT_INSTANTIATE_GROUP_SHADE5B)
+SPT_KERNELS_SHADE5B(SPT_DEFINE_KERNEL)
 #else
 SPT_KERNELS_PRIMARY(SPT_DECLARE_KERNEL)
 SPT_KERNELS_RAYS(SPT_DECLARE_KERNEL)
 SPT_KERNELS_STREAM(SPT_DECLARE_KERNEL)
-SPT_KERNELS_BEZ(SPT_DECLARE_KERNEL)
-SPT_KERNELS_WST(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE0(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE1(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE2(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE3A(SPT_DECLARE_KERNEL)
 SPT_KERNELS_SHADE3B(SPT_DECLARE_KERNEL)
+SPT_KERNELS_SHADE4(SPT_DECLARE_KERNEL)
+SPT_KERNELS_SHADE5A(SPT_DECLARE_KERNEL)
+SPT_KERNELS_SHADE5B(SPT_DECLARE_KERNEL)
 #endif

@@ -112,7 +112,6 @@ struct RenderCtx {
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
     uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
-    BezPairs bzs, bze;                      // deferred patch tests of the shadow / extension rays (bezier_pairs.h; rec == null: off)
     const int2* row_span;                   // per image row: first / last pixel that can see an instance (null: only the rectangle above)
     uint32_t debug_normal;                  // SPT_RENDER_DEBUG_NORMAL: the reference's `debug_normal` feature (pt.rs:113-118)
 };
@@ -392,10 +391,15 @@ SPT_DEV void rad_store(const RenderCtx& rc, uint32_t slot, f3 c) {
 // last bounce.  The host picks it when the previous pass showed that few paths are left after bounce 0 (cfg2: a cube in
 // the void): the 2 x 6 launches of bounces 2 .. 7, each ~9.5 us of dispatch for nothing, are never made.  Same
 // arithmetic per path, the same additions to its radiance slot in the same order; the queue counters still count.
+#ifndef SPT_SHADE_HEAVY_WAVES
+#define SPT_SHADE_HEAVY_WAVES 2   // waves / SIMD the probe-only (kFeat 3) and glint-only (kFeat 4) kernels are compiled for: unbounded they need
+                                  // 248 - 266 resp. 284 - 300 VGPRs, i.e. mostly ONE wave; bounded to 256 a few registers spill (measured: DESIGN.md)
+#endif
 template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab, bool kLoop = false>
-__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : 1) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : ((kFeat == 3 || kFeat == 4) ? SPT_SHADE_HEAVY_WAVES : 1)) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     static_assert(!kLoop || (kFused && !kFirst), "the in-kernel bounce loop exists for the fused kernels of bounce >= 1");
-    constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3;
+    // kFeat 3: Subsurface substrates (the probe), 4: position-normal distributions (the glint walks), 5: both
+    constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3 || kFeat == 5, kPndf = kFeat == 4 || kFeat == 5;
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
     // workgroups of an empty shard (most of them in the late bounces) leave before staging anything into LDS;
@@ -631,7 +635,7 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                 } else {  // pt.rs:112-193
                     const spt_surface sf = load_surface<kTab>(sc, it.surface);
                     const uint32_t sflags = sf.flags;
-                    DMat mt = material_at<kTex, kTab>(sc, sf.material, it);
+                    DMat mt = material_at<kTex, kTab, kPndf>(sc, sf.material, it);
                     if (kSimple) mt.bxdf = SPT_BXDF_LAMBERT;
                     DCoord coord = surface_coord<kTex>(sc, sf, ray, it);
                     f3 po = it.position;
@@ -648,7 +652,7 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                         ssio.has = false;
                         ssio.po = po;
                         ssio.coord_po = coord;
-                        samp = mat_sample<true, kGeoLds, kTab>(mt, wo, rng, &sc, &ssio);
+                        samp = mat_sample<true, kGeoLds, kTab, kPndf>(mt, wo, rng, &sc, &ssio);
                         if (ssio.has) {  // pt.rs:147-151
                             po = ssio.pi;
                             coord = ssio.coord_pi;
@@ -659,7 +663,8 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                         samp.wi = reflect_z(wo); samp.f = gray(1.0f); samp.pdf = 1.0f; samp.transmit = false;
                         (void)rng.next();
 #else
-                        samp = mat_sample(mt, wo, rng);
+                        if (kPndf) samp = mat_sample<false, false, kTab, true>(mt, wo, rng, &sc);
+                        else samp = mat_sample(mt, wo, rng);
 #endif
                     }
                     lsi = po;
@@ -671,8 +676,9 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                         DLightSample ls;
                         if (sample_light<kSimple, kTex, kTab>(sc, lsi, rng, &ls)) {
                             f3 wi = coord.to_local(ls.dir);
-                            f3 f = mat_eval<kSubsurface>(mt, wo, wi, &sc);
-                            float mpdf = mat_pdf<kSubsurface>(mt, wo, wi, &sc);
+                            DPndfMemo memo{0.0f, false};    // bxdf() and pdf() of a glint lobe share one tree walk
+                            f3 f = mat_eval<kPndf>(mt, wo, wi, &sc, &memo);
+                            float mpdf = mat_pdf<kPndf>(mt, wo, wi, &sc, &memo);
                             if (ls.pdf != 0.0f && spt_is_finite(ls.pdf)) {
                                 f3 li;
                                 if (ls.is_delta) {
@@ -995,7 +1001,6 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
     wk.cur = kNoRef;
     bool busy = false, drained = false;
     uint32_t idx = 0;
-    BezDefer bd{rc.bzs.rec, rc.bzs.ctl, rc.bzs.cap, 0u, 0u};    // (null in the plain library and when deferral is off)
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
     for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
@@ -1007,36 +1012,20 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
                 DRay r;
                 r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
                 wk.begin(sc, r, b.w);
-                bd.ray = idx; bd.pushed = 0u;
                 busy = true;
             }
             // the cursor only grows: once any lane was refused the shard is empty for good
             drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
         }
         if (__ballot(busy) == 0ull) break;
-        wk.run(sc, rc.stream_rounds, spill_mem, bd);
-        bool defer = false;
-        (void)defer;
+        wk.run(sc, rc.stream_rounds, spill_mem);
         if (busy && wk.done) {
-            if (wk.h.inst < 0) {  // not occluded (by anything but the patches whose tests were parked)
-                if (SPT_WITH_BEZIER && bd.pushed != 0u) {
-                    defer = true;
-                } else {
-                    const float4 c = rc.shadow.contrib_slot[idx];
-                    rad_add(rc, __float_as_uint(c.w), mk3(c));
-                }
+            if (wk.h.inst < 0) {  // not occluded
+                const float4 c = rc.shadow.contrib_slot[idx];
+                rad_add(rc, __float_as_uint(c.w), mk3(c));
             }
             busy = false;
         }
-#if SPT_WITH_BEZIER
-        if (rc.bzs.rec != nullptr) {     // (wave-uniform) the ray waits for its pairs: k_bezier_finish_shadow adds its term or not
-            const uint32_t j = wave_push(defer, rc.bzs.ctl + 2u + shard);
-            if (defer) {
-                rc.bzs.occluded[idx] = 0;
-                rc.bzs.def_list[(size_t)qbase + j] = idx;
-            }
-        }
-#endif
     }
     if (kCount) flush_visits(rc, wk.vc, 1u);
 }
@@ -1055,7 +1044,6 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
     wk.cur = kNoRef;
     bool busy = false, drained = false, in_medium = false;
     uint32_t idx = 0;
-    BezDefer bd{rc.bze.rec, rc.bze.ctl, rc.bze.cap, 0u, 0u};    // (null in the plain library and when deferral is off)
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
     for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
@@ -1068,29 +1056,14 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
                 DRay r;
                 r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
                 wk.begin(sc, r, SPT_F32_MAX);
-                bd.ray = idx; bd.pushed = 0u;
                 busy = true;
             }
             drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
         }
         if (__ballot(busy) == 0ull) break;
-        wk.run(sc, rc.stream_rounds, spill_mem, bd);
+        wk.run(sc, rc.stream_rounds, spill_mem);
         bool retire = busy && wk.done;
         bool keep = false;
-#if SPT_WITH_BEZIER
-        if (rc.bze.rec != nullptr) {     // (wave-uniform) a ray with parked patch tests leaves what the walk found and waits:
-            const bool defer = retire && bd.pushed != 0u;      // k_bezier_finish_extend ends it
-            const uint32_t j = wave_push(defer, rc.bze.ctl + 2u + shard);
-            if (defer) {
-                rc.bze.def_hit[idx] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
-                rc.bze.def_inst[idx] = wk.h.inst;
-                rc.bze.key[idx] = ~0ull;
-                rc.bze.def_list[(size_t)qbase + j] = idx;
-                busy = false;
-                retire = false;
-            }
-        }
-#endif
         if (retire) {
             if (wk.h.inst >= 0 || in_medium) {
                 keep = true;
@@ -1144,7 +1117,6 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
     const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
     const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
     uint2 spill_mem[kSpillStack];
-    BezDefer no_defer{nullptr, nullptr, 0u, 0u, 0u};   // camera rays test a patch where they meet it (coherent: the walker is full)
     SWalker<true, kCount> wk;
     wk.vc = LaneVisits{0u, 0u, 0u};
     wk.done = true;
@@ -1186,7 +1158,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
             }
         }
         if (__ballot(busy) == 0ull) break;
-        wk.run(sc, rc.stream_rounds, spill_mem, no_defer);
+        wk.run(sc, rc.stream_rounds, spill_mem);
         const bool retire = busy && wk.done;
         const bool hit = retire && wk.h.inst >= 0;
         const size_t ri = (size_t)s_cur * rc.n_pixels + lp;
@@ -1231,5 +1203,3 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
     }
 }
 
-#include "wst.h"   // kind-sorted traversal (uses the queue / context definitions above)
-#include "bezier_pairs.h"   // deferred patch tests (Bezier library only)

@@ -521,7 +521,8 @@ SPT_DEV float fresnel_moment1(float eta) {  // src/bxdf/util.rs:123-134
 }
 // MaterialT::bxdf_context at a hit (src/material/{lambert,conductor,dielectric,plastic,pbr_metallic,pbr_specular}.rs):
 // constant materials were folded by the loader; a material with an image-backed parameter carries a recipe.
-template <bool kTex, bool kL = false>
+// kPndf: position-normal-distribution recipes can occur (k_shade<4 | 5>): only then is their footprint walk compiled in
+template <bool kTex, bool kL = false, bool kPndf = false>
 SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
     DMat d = load_material<kL>(sc, m);
     if (!kTex) return d;
@@ -606,7 +607,7 @@ SPT_DEV DMat material_at(const DScene& sc, uint32_t m, const DInter& it) {
             d.fresnel = SPT_FRESNEL_SCHLICK;
             d.bxdf = specular ? SPT_BXDF_SPECULAR_CONDUCTOR : SPT_BXDF_MICROFACET_CONDUCTOR;
         }
-        if (sc.pndfs != nullptr) {
+        if (kPndf && sc.pndfs != nullptr) {
             const spt_pndf& pd = sc.pndfs[r0.z];
             const float ux = spt_pndf_wrap(it.uv[0] * pd.tiling[0] + pd.offset[0]), uy = spt_pndf_wrap(it.uv[1] * pd.tiling[1] + pd.offset[1]);
             const float dxx = it.duvdx[0] * pd.tiling[0], dxy = it.duvdx[1] * pd.tiling[1];
@@ -668,8 +669,21 @@ SPT_DEV float pndf_half_pdf(const DScene& sc, const DMat& m, f3 half) {   // mic
     const spt_pndf_view v = pndf_view(sc, m);
     return spt_pndf_calc(&v, m.c1.y, spt_pndf_term_coe(v.pd, m.c1.x), m.ax, m.ay, half.x, half.y);
 }
-SPT_DEV float pndf_ndf_visible(const DScene& sc, const DMat& m, f3 wo, f3 wi, f3 half) {   // microfacet.rs:156-169
-    const float pndf = pndf_half_pdf(sc, m, half);
+// The light sample of a path vertex asks bxdf(wo, wi) and pdf(wo, wi) of the same lobe for the same pair: both need the
+// density of the same half vector, i.e. the same walk of the block's 4-D tree with the same arguments (the reference walks
+// twice, microfacet.rs:142-169).  The first of the two leaves the value here, the second takes it: same bits, one walk.
+struct DPndfMemo {
+    float d;
+    bool have;
+};
+SPT_DEV float pndf_half_pdf(const DScene& sc, const DMat& m, f3 half, DPndfMemo* memo) {
+    if (memo != nullptr && memo->have) return memo->d;
+    const float d = pndf_half_pdf(sc, m, half);
+    if (memo != nullptr) { memo->d = d; memo->have = true; }
+    return d;
+}
+SPT_DEV float pndf_ndf_visible(const DScene& sc, const DMat& m, f3 wo, f3 wi, f3 half, DPndfMemo* memo = nullptr) {   // microfacet.rs:156-169
+    const float pndf = pndf_half_pdf(sc, m, half, memo);
     const float visible = 0.25f / spt_max(wi.z * wo.z, 0.0001f);
     return pndf / spt_max(half.z, 0.0001f) * visible;
 }
@@ -783,8 +797,10 @@ SPT_DEV bool subsurface_probe(const DScene& sc, const DMat& m, DRng& rng, DSubsu
     return true;
 }
 
-// kSS: Subsurface substrates can occur (k_shade<2>); sc / io are only touched then
-template <bool kSS = false, bool kGeoLds = false, bool kL = false>
+// kSS: Subsurface substrates can occur (k_shade<3 | 5>: the BSSRDF probe is traced in here); kPndf: position-normal-distribution
+// lobes can occur (k_shade<4 | 5>: tree walks with a 32-entry private stack).  sc / io are only touched then.  Two flags, so
+// that a scene with one of the two features does not pay the registers of the other (round 2: one kernel for both, 374 VGPRs).
+template <bool kSS = false, bool kGeoLds = false, bool kL = false, bool kPndf = kSS>
 SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc = nullptr, DSubsurfaceIo* io = nullptr) {
     DBxdfSample s;
     s.transmit = false;
@@ -814,7 +830,7 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
         break;
     }
     case SPT_BXDF_PNDF_CONDUCTOR: {  // MicrofacetConductor::sample (microfacet_conductor.rs:23-42) over a PndfMicrofacet
-        if (kSS) {
+        if (kPndf) {
             float half_pdf;
             f3 half = pndf_sample_half(*sc, m, rng, &half_pdf);
             f3 fr = mat_fresnel(m, wo, half);
@@ -882,7 +898,7 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
     case SPT_BXDF_PNDF_PLASTIC:
     case SPT_BXDF_MICROFACET_PLASTIC:
     case SPT_BXDF_SPECULAR_PLASTIC: {  // microfacet_plastic.rs:26-79, specular_plastic.rs:19-63
-        const bool glint = kSS && m.bxdf == SPT_BXDF_PNDF_PLASTIC;   // the same lobe over a PndfMicrofacet
+        const bool glint = kPndf && m.bxdf == SPT_BXDF_PNDF_PLASTIC;   // the same lobe over a PndfMicrofacet
         const bool rough = m.bxdf == SPT_BXDF_MICROFACET_PLASTIC || glint;
         f3 fresnel_macro = plastic_fresnel(m, wo, mk3(0, 0, 1));
         float specular_weight = luminance(fresnel_macro);
@@ -964,14 +980,14 @@ SPT_DEV DBxdfSample mat_sample(const DMat& m, f3 wo, DRng& rng, const DScene* sc
     return s;
 }
 
-// kSS (k_shade<3>): position-normal distributions can occur; sc is only touched then
-template <bool kSS = false>
-SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
+// kPndf (k_shade<4 | 5>): position-normal distributions can occur; sc is only touched then
+template <bool kPndf = false>
+SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr, DPndfMemo* memo = nullptr) {
     switch (m.bxdf) {
     case SPT_BXDF_PNDF_CONDUCTOR:  // microfacet_conductor.rs:44-53
-        if (kSS && wo.z * wi.z >= 0.0f) {
+        if (kPndf && wo.z * wi.z >= 0.0f) {
             f3 half = half_from_reflect(wo, wi);
-            return pndf_half_pdf(*sc, m, half) / (4.0f * spt_abs(dot(wo, half)));
+            return pndf_half_pdf(*sc, m, half, memo) / (4.0f * spt_abs(dot(wo, half)));
         }
         return 1.0f;
     case SPT_BXDF_LAMBERT:  // lambert.rs:38-44
@@ -1011,9 +1027,9 @@ SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
         float substrate_weight = luminance((gray(1.0f) - fresnel_macro) * m.c0);
         float reflect_pdf = specular_weight / (specular_weight + substrate_weight);
         float specular_pdf;
-        if (kSS && m.bxdf == SPT_BXDF_PNDF_PLASTIC) {
+        if (kPndf && m.bxdf == SPT_BXDF_PNDF_PLASTIC) {
             f3 half = half_from_reflect(wo, wi);
-            specular_pdf = reflect_pdf * pndf_half_pdf(*sc, m, half) / (4.0f * spt_abs(dot(wo, half)));
+            specular_pdf = reflect_pdf * pndf_half_pdf(*sc, m, half, memo) / (4.0f * spt_abs(dot(wo, half)));
         } else if (m.bxdf == SPT_BXDF_MICROFACET_PLASTIC) {
             f3 half = half_from_reflect(wo, wi);
             specular_pdf = reflect_pdf * ggx_vndf_pdf(half, wo, m.ax, m.ay) / (4.0f * spt_abs(dot(wo, half)));
@@ -1027,13 +1043,13 @@ SPT_DEV float mat_pdf(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
     }
 }
 
-template <bool kSS = false>
-SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
+template <bool kPndf = false>
+SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr, DPndfMemo* memo = nullptr) {
     switch (m.bxdf) {
     case SPT_BXDF_PNDF_CONDUCTOR:  // microfacet_conductor.rs:55-64
-        if (kSS && wo.z * wi.z >= 0.0f) {
+        if (kPndf && wo.z * wi.z >= 0.0f) {
             f3 half = half_from_reflect(wo, wi);
-            return mat_fresnel(m, wo, half) * pndf_ndf_visible(*sc, m, wo, wi, half);
+            return mat_fresnel(m, wo, half) * pndf_ndf_visible(*sc, m, wo, wi, half, memo);
         }
         return gray(0.0f);
     case SPT_BXDF_LAMBERT:  // lambert.rs:46-52
@@ -1077,8 +1093,8 @@ SPT_DEV f3 mat_eval(const DMat& m, f3 wo, f3 wi, const DScene* sc = nullptr) {
     case SPT_BXDF_MICROFACET_PLASTIC: {  // microfacet_plastic.rs:101-118
         if (!(wo.z * wi.z >= 0.0f)) return gray(0.0f);
         f3 half = half_from_reflect(wo, wi);
-        const bool glint = kSS && m.bxdf == SPT_BXDF_PNDF_PLASTIC;
-        f3 refl = plastic_fresnel(m, wo, half) * (glint ? pndf_ndf_visible(*sc, m, wo, wi, half) : ndf_visible(m, wo, wi, half));
+        const bool glint = kPndf && m.bxdf == SPT_BXDF_PNDF_PLASTIC;
+        f3 refl = plastic_fresnel(m, wo, half) * (glint ? pndf_ndf_visible(*sc, m, wo, wi, half, memo) : ndf_visible(m, wo, wi, half));
         f3 sub = (gray(1.0f) - plastic_fresnel(m, wo, mk3(0, 0, 1))) * substrate_eval(m, wo, wi);
         return refl + sub;
     }

@@ -529,9 +529,7 @@ struct spt_scene {
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, slot_bits, out;
-    DeviceBuffer trace_in, trace_out, visits, wst_ovf;
-    // deferred patch tests (bezier_pairs.h; the Bezier library only): [0] shadow rays, [1] extension rays
-    DeviceBuffer bz_rec[2], bz_ctl[2], bz_def_list[2], bz_occluded, bz_def_hit, bz_def_inst, bz_key, bz_def_uv;
+    DeviceBuffer trace_in, trace_out, visits;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
@@ -545,7 +543,9 @@ struct spt_scene {
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
     bool lds_tables = false;  // the shading tables fit LDS behind the geometry (k_shade<.., kTab>)
     bool fused = false;     // k_shade<0, ., kFused> can run: lds_tables and a simple scene
-    bool subsurface = false;  // some material has a Subsurface substrate (k_shade<3, .>)
+    bool subsurface = false;  // the heavy shade levels are needed: some material has a Subsurface substrate (probe) and / or glints
+    bool has_probe = false;   // ... a Subsurface substrate: k_shade<3 | 5, .> (the BSSRDF probe walks the BVH inside the shade kernel)
+    bool has_pndf = false;    // ... a position-normal distribution: k_shade<4 | 5, .> (tree walks with private stacks)
     DeviceBuffer ss_cdf;
     DeviceBuffer pndfs, pndf_terms, pndf_nodes, pndf_refs, pndf_roots;   // position-normal distributions (k_shade<3, .> too)
     bool textured = false;  // a material recipe, normal map or emissive map samples textures per hit (k_shade<2, .>)
@@ -1108,8 +1108,10 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         for (uint32_t i = 0; i < s.n_surfaces; ++i) textured = textured || s.surfaces[i].normal_map != 0 || s.surfaces[i].emissive_map != 0;
         for (uint32_t i = 0; i < s.n_materials; ++i) sc->subsurface = sc->subsurface || s.materials[i].substrate == SPT_SUBSTRATE_SUBSURFACE;
         for (uint32_t i = 0; i < s.n_material_recipes; ++i) sc->subsurface = sc->subsurface || s.material_recipes[i].type == SPT_MAT_SUBSURFACE;
-        if (s.n_pndfs != 0) {   // glints ride in the heavy variant too: their tree walks would cost k_shade<2> its registers
+        sc->has_probe = sc->subsurface;
+        if (s.n_pndfs != 0) {   // glints get a heavy variant of their own: their tree walks would cost k_shade<2> its registers
             sc->subsurface = true;
+            sc->has_pndf = true;
             sc->pndfs.upload(s.pndfs, s.n_pndfs);
             sc->pndf_terms.upload(s.pndf_terms, s.n_pndf_terms);
             sc->pndf_nodes.upload(s.pndf_nodes, s.n_pndf_nodes);
@@ -1595,34 +1597,6 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.visits = sc->visits.as<unsigned long long>();
             rc.debug_normal = (p.flags & SPT_RENDER_DEBUG_NORMAL) ? 1u : 0u;
             rc.row_span = row_span_dev;
-#if SPT_WITH_BEZIER
-            // SPT_BEZ_DEFER=1: the patch tests of the shadow / extension rays leave the streaming walkers for a clipping kernel
-            // of their own (bezier_pairs.h).  Opt-in: bit-identical, and MEASURED slower than testing a patch where the walker
-            // meets it (t_bezier.json 132 vs 130 ms, t_catmull.json 196 vs 181 ms; why: profiles/r02_experiments.md)
-            if (sc->swalk && !sc->lds_geo && sc->d.bez != nullptr && !sc->bez_newton && std::getenv("SPT_BEZ_DEFER") != nullptr) {
-                const size_t pairs_cap = (size_t)std::min<uint64_t>(4ull * cap, 1ull << 28);
-                for (int k = 0; k < 2; ++k) {
-                    sc->bz_rec[k].ensure(pairs_cap * 48);
-                    sc->bz_ctl[k].ensure((2 + kShards) * sizeof(uint32_t));
-                    sc->bz_def_list[k].ensure(cap * sizeof(uint32_t));
-                }
-                sc->bz_occluded.ensure(cap);
-                sc->bz_def_hit.ensure(cap * 16);
-                sc->bz_def_inst.ensure(cap * 4);
-                sc->bz_key.ensure(cap * 8);
-                sc->bz_def_uv.ensure(cap * 16);
-                BezPairs bp{};
-                bp.cap = (uint32_t)pairs_cap;
-                bp.occluded = sc->bz_occluded.as<uint8_t>();
-                bp.def_hit = sc->bz_def_hit.as<float4>();
-                bp.def_inst = sc->bz_def_inst.as<int32_t>();
-                bp.key = sc->bz_key.as<unsigned long long>();
-                bp.def_uv = sc->bz_def_uv.as<float4>();
-                rc.bzs = bp; rc.bze = bp;
-                rc.bzs.rec = sc->bz_rec[0].as<float4>(); rc.bzs.ctl = sc->bz_ctl[0].as<uint32_t>(); rc.bzs.def_list = sc->bz_def_list[0].as<uint32_t>();
-                rc.bze.rec = sc->bz_rec[1].as<float4>(); rc.bze.ctl = sc->bz_ctl[1].as<uint32_t>(); rc.bze.def_list = sc->bz_def_list[1].as<uint32_t>();
-            }
-#endif
             // tiles of this shard that intersect the screen-space bound (all of them with an environment)
             uint32_t active_tiles = pix_blocks;
             uint64_t live_pixels = n_pix;
@@ -1683,11 +1657,6 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 // 8.8 -> 12.4 ms and shadow rays 9.8 -> 11.3 ms (coherent / short walks: the state machine's tighter loop wins)
                 const uint32_t stream_mask = env_u32("SPT_STREAM_MASK", SPT_WITH_BEZIER ? 6u : 4u);   // (patch scenes: shadow rays too, 214 -> 197 ms on t_catmull.json)
                 const bool stream_p = stream && (stream_mask & 1u), stream_s = stream && (stream_mask & 2u), stream_e = stream && (stream_mask & 4u);
-                // kind-sorted traversal (wst.h) for the shadow / extension rays: 1 shadow, 2 extend
-                // (opt-in experiment, see DESIGN.md: its barrier-synchronous rounds are latency-starved - 180 - 215 ms vs 94)
-                const uint32_t wst_mask = stream ? env_u32("SPT_WST_MASK", 0u) : 0u;
-                const uint32_t wst_grid = kShards * kWstBlocksPerShard;
-                if (wst_mask) sc->wst_ovf.ensure((size_t)wst_grid * kWstRays * kSpillStack * sizeof(uint2));   // per slot: the levels beyond kWstStack (fewer than kSpillStack)
                 rc.slot_bits = nullptr;
                 if (rc.primary_chunks > 1u || collect) {   // collect: every sample owns a slot, which is what the chunked kernel does
                     chunked_any = true;
@@ -1728,7 +1697,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     RenderCtx ru = rc;
                     if (b & 1u) std::swap(ru.qa, ru.qb);
                     const bool tab = sc->lds_tables && std::getenv("SPT_NO_LDS_TABLES") == nullptr;   // shading tables from LDS (tab_ld)
-                    const size_t shade_lds = sc->subsurface ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3>: traversal stack
+                    const size_t shade_lds = sc->has_probe ? lds : 0;   // the BSSRDF probe walks the BVH inside k_shade<3 | 5>: traversal stack
 #define SPT_LAUNCH_SHADE(FEAT)                                                                                                                 \
         if (tab) {                                                                                                                                 \
             if (b == 0) hipLaunchKernelGGL((k_shade<FEAT, true, false, true, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);  \
@@ -1738,8 +1707,12 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             else hipLaunchKernelGGL((k_shade<FEAT, false, false, false, false>), dim3(kPersistentBlocks), dim3(kBlock), shade_lds, st, sc->d, ru, b);       \
         }
                     if (sc->simple) { SPT_LAUNCH_SHADE(0) } else if (!sc->textured) { SPT_LAUNCH_SHADE(1) } else if (!sc->subsurface) { SPT_LAUNCH_SHADE(2) }
-                    else if (tab || !L) { SPT_LAUNCH_SHADE(3) }
-                    else {   // geometry in LDS, tables not: the probe still walks the LDS copy (k_shade's kGeoLds)
+                    else if (!sc->has_probe) { SPT_LAUNCH_SHADE(4) }          // glints only: no probe, so the geometry's place does not matter
+                    else if (tab || !L) { if (sc->has_pndf) { SPT_LAUNCH_SHADE(5) } else { SPT_LAUNCH_SHADE(3) } }
+                    else if (sc->has_pndf) {   // geometry in LDS, tables not: the probe still walks the LDS copy (k_shade's kGeoLds)
+                        if (b == 0) hipLaunchKernelGGL((k_shade<5, true, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else hipLaunchKernelGGL((k_shade<5, false, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                    } else {
                         if (b == 0) hipLaunchKernelGGL((k_shade<3, true, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else hipLaunchKernelGGL((k_shade<3, false, false, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                     }
@@ -1756,18 +1729,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         HIP_CHECK(hipStreamWaitEvent(ss, sc->ev_fork, 0));
                     }
                     begin(SPT_K_SHADOW);
-                    if ((wst_mask & 1u) && count) hipLaunchKernelGGL((k_trace_wst<WstShadow, true>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, ss, sc->d, ru, b, sc->wst_ovf.as<uint2>());
-                    else if (wst_mask & 1u) hipLaunchKernelGGL((k_trace_wst<WstShadow, false>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, ss, sc->d, ru, b, sc->wst_ovf.as<uint2>());
-#if SPT_WITH_BEZIER
-                    else if (stream_s && ru.bzs.rec != nullptr) {      // walk, clip the parked (ray, patch) pairs, end the rays that waited
-                        HIP_CHECK(hipMemsetAsync(ru.bzs.ctl, 0, (2 + kShards) * sizeof(uint32_t), ss));
-                        if (count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
-                        else hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
-                        hipLaunchKernelGGL(k_bezier_pairs<false>, dim3(kDynBlocks), dim3(kBlock), 0, ss, sc->d, ru.bzs);
-                        hipLaunchKernelGGL(k_bezier_finish_shadow<0>, dim3(kPersistentBlocks), dim3(kBlock), 0, ss, ru, ru.bzs);
-                    }
-#endif
-                    else if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (stream_s) hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (dyn_shadow && count) hipLaunchKernelGGL(k_shadow_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
@@ -1778,19 +1740,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     if (side) HIP_CHECK(hipEventRecord(sc->ev_join, ss));
                     if (b + 1 < p.max_depth) {
                         begin(SPT_K_EXTEND);
-                        if ((wst_mask & 2u) && count) hipLaunchKernelGGL((k_trace_wst<WstExtend, true>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, st, sc->d, ru, b, sc->wst_ovf.as<uint2>());
-                        else if (wst_mask & 2u) hipLaunchKernelGGL((k_trace_wst<WstExtend, false>), dim3(wst_grid), dim3(kWstRays), kWstLdsBytes, st, sc->d, ru, b, sc->wst_ovf.as<uint2>());
-#if SPT_WITH_BEZIER
-                        else if (stream_e && ru.bze.rec != nullptr) {
-                            HIP_CHECK(hipMemsetAsync(ru.bze.ctl, 0, (2 + kShards) * sizeof(uint32_t), st));
-                            if (count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
-                            else hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
-                            hipLaunchKernelGGL(k_bezier_pairs<true>, dim3(kDynBlocks), dim3(kBlock), 0, st, sc->d, ru.bze);
-                            hipLaunchKernelGGL(k_bezier_commit<0>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, ru.bze);
-                            hipLaunchKernelGGL(k_bezier_finish_extend<0>, dim3(kPersistentBlocks), dim3(kBlock), 0, st, sc->d, ru, ru.bze, b);
-                        }
-#endif
-                        else if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (stream_e) hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (dyn_extend && count) hipLaunchKernelGGL(k_extend_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);

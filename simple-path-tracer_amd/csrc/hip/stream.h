@@ -26,35 +26,6 @@
 #pragma once
 #include "trace.h"
 
-// ---- deferred Bezier-patch tests (bezier_pairs.h; the structs live here because the walker below takes them) ----------
-// 3 x float4 per pair: (o, t_min) (d, limit) (patch, ray, instance, result flag); after the clipping (t, u, v) replace o
-struct BezPairs {
-    float4* rec;                 // null: no deferral (every patch is tested where it is met)
-    uint32_t* ctl;               // [0] pairs pushed, [1] consume cursor, [2 + shard] deferred rays of the shard
-    uint32_t cap;
-    uint32_t* def_list;          // per shard (shard * shard_cap + j): queue indices of the rays that wait for pairs
-    // shadow rays: one byte per queue entry, set by a pair that is accepted
-    uint8_t* occluded;
-    // extension rays: what the walk found without the patches, and the best patch candidate
-    float4* def_hit;             // (t, v, w, prim) of the non-patch closest hit
-    int32_t* def_inst;           // its instance, -1 = none
-    unsigned long long* key;     // min over accepted pairs of (t bits << 32 | instance); ~0 = none
-    float4* def_uv;              // (u, v, prim, -) of the pair that owns `key`
-};
-
-// what a walker needs to park a patch test: passed by value through SWalker::run (a pointer to it would be generic)
-struct BezDefer {
-    float4* rec;
-    uint32_t* count;
-    uint32_t cap;
-    uint32_t ray;                // queue index of the lane's current ray
-    uint32_t pushed;             // pairs recorded for it
-};
-
-#if SPT_WITH_BEZIER
-SPT_DEV bool bez_defer_push(BezDefer& bd, const DRay& orr, float limit, uint32_t inst, uint32_t prim_id);   // bezier_pairs.h
-#endif
-
 constexpr uint32_t kNoRef = 0xffffffffu;     // "nothing in hand": the next thing comes off the stack
 constexpr uint32_t kInTlas = 0xffffffffu;    // blas_base while the walk is in the TLAS
 constexpr float kRelaxLo = 0.9999996f;       // 1 - 4e-7 (rounded): entry distances are lowered,
@@ -271,8 +242,7 @@ struct SWalker {
 
     // a TLAS leaf: transform the ray into the instance (Instance::intersect, instance.rs:88-109) and either test its
     // sphere / patch right away or enter its BLAS
-    SPT_DEV void instance_step(const DScene& sc, uint2* spill, BezDefer& bd) {
-        (void)bd;
+    SPT_DEV void instance_step(const DScene& sc, uint2* spill) {
         const uint32_t slot = leaf_first(cur), count = leaf_count(cur);
         if (count > 1u) push(kLeaf | ((count - 1u) << 27) | (slot + 1u), -spt_inf(), spill);   // the leaf's other instances: next
         const float4* ip = sc.geo + (sc.o_sinst + 6u * slot);
@@ -305,10 +275,6 @@ struct SWalker {
         }
 #if SPT_WITH_BEZIER
         if (prim_type == SPT_PRIM_BEZIER) {   // bezier.rs:152-174; the patch parameters ride in the hit's (v, w)
-            if (bez_defer_push(bd, orr, h.t, inst, prim_id)) {     // parked: the pair is clipped by k_bezier_pairs
-                pop_next(spill);
-                return;
-            }
             float u, v, t;
             const bool got = bezier_intersect_ray(sc.bez + 16u * prim_id, orr, &u, &v, &t) && t > orr.t_min;
             if (kClosest) {
@@ -335,12 +301,12 @@ struct SWalker {
 
     // if-if: one node step for every lane that holds an inner node, then one leaf step for every lane that holds a leaf
     // (including the lanes whose node step just produced one); `rounds` times
-    SPT_DEV void run_ifif(const DScene& sc, uint32_t rounds, uint2* spill, BezDefer& bd) {
+    SPT_DEV void run_ifif(const DScene& sc, uint32_t rounds, uint2* spill) {
         for (uint32_t r = 0; r < rounds; ++r) {
             if (__ballot(!done) == 0ull) break;
             if (!done && cur < kLeaf) node_step(sc, spill);
             if (!done && cur != kNoRef && cur >= kLeaf) {
-                if (blas_base == kInTlas) instance_step(sc, spill, bd);
+                if (blas_base == kInTlas) instance_step(sc, spill);
                 else if (leaf_count(cur) <= 4u) tri_leaf_step(sc, spill);
                 else tri_leaf_long(sc, spill);
             }
@@ -348,8 +314,8 @@ struct SWalker {
     }
 
     // while-while: node loop until no lane of the wave holds an inner node, then one leaf round; `rounds` times
-    SPT_DEV void run(const DScene& sc, uint32_t rounds, uint2* spill, BezDefer& bd) {
-        if (rounds & 0x100u) { run_ifif(sc, rounds & 0xffu, spill, bd); return; }
+    SPT_DEV void run(const DScene& sc, uint32_t rounds, uint2* spill) {
+        if (rounds & 0x100u) { run_ifif(sc, rounds & 0xffu, spill); return; }
         for (uint32_t r = 0; r < rounds; ++r) {
             // (bounded: a descent is at most the tree depth long, pops included a few times that; the bound only makes
             // sure that a corrupt tree can never keep a wave in here for ever)
@@ -361,7 +327,7 @@ struct SWalker {
             const bool leaf = !done && cur != kNoRef;     // every live lane holds a leaf (or nothing) here
             if (__ballot(leaf) == 0ull) break;
             if (leaf) {
-                if (blas_base == kInTlas) instance_step(sc, spill, bd);
+                if (blas_base == kInTlas) instance_step(sc, spill);
                 else if (leaf_count(cur) <= 4u) tri_leaf_step(sc, spill);
                 else tri_leaf_long(sc, spill);
             }

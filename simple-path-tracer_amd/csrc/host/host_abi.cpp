@@ -65,6 +65,12 @@ spt_status spt_host_load_scene(const char* scene_json_path, spt_host_scene** out
 
 const spt_scene_desc* spt_host_scene_desc(const spt_host_scene* scene) { return scene ? &scene->hs->desc : nullptr; }
 
+spt_status spt_host_scene_set_bezier_newton(spt_host_scene* scene, int32_t newton) {
+    if (!scene) { set_error("scene_set_bezier_newton: null argument"); return SPT_ERR_INVALID_ARG; }
+    for (spt_bezier_patch& bp : scene->hs->bezier_patches) bp.cp[0][0][3] = newton ? SPT_BEZIER_NEWTON : 0.0f;   // the desc points at this array
+    return SPT_OK;
+}
+
 // Scene::get_camera (src/core/scene.rs:29-41): by name, or the only one
 spt_status spt_host_scene_camera(const spt_host_scene* scene, const char* name, spt_camera* out) {
     if (!scene || !out) { set_error("scene_camera: null argument"); return SPT_ERR_INVALID_ARG; }

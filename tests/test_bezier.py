@@ -184,3 +184,24 @@ def test_newton_iteration_build_of_the_patch_test(tmp_path, monkeypatch):
     # any-hit agrees with closest-hit on the same rays (t_max = inf)
     occ = _util.oracle_trace_any(sc, rays)
     assert np.array_equal(occ.astype(bool), n)
+
+
+def test_newton_patch_test_is_a_per_scene_option():
+    """ADVICE round 2: the reference's `bezier_ni` build used to be selectable only through a process-wide environment variable;
+    `load_scene(..., bezier_newton=)` sets it per scene (spt_host_scene_set_bezier_newton), two scenes of one process may differ."""
+    path = os.path.join(_util.SCENES, "t_bezier.json")
+    os.environ.pop("SPT_BEZIER_NI", None)
+    plain, newton, clip = spt.load_scene(path), spt.load_scene(path, bezier_newton=True), spt.load_scene(path, bezier_newton=False)
+    sel = lambda sc: {float(sc.desc.bezier_patches[i].cp[0][0][3]) for i in range(sc.desc.n_bezier_patches)}
+    assert plain.desc.n_bezier_patches > 0
+    assert sel(plain) == {0.0} and sel(newton) == {1.0} and sel(clip) == {0.0}
+    os.environ["SPT_BEZIER_NI"] = "1"       # the environment stays the DEFAULT only
+    try:
+        assert sel(spt.load_scene(path)) == {1.0} and sel(spt.load_scene(path, bezier_newton=False)) == {0.0}
+    finally:
+        os.environ.pop("SPT_BEZIER_NI", None)
+    # the two routines are different answers (one root from the middle of the patch vs every root of the clipping), both finite
+    r = spt.PathTracer(max_depth=3, sampler=spt.SAMPLER_RANDOM, spp=2, seed=3)
+    a, _ = _util.oracle_render(plain, r, 48, 36, camera="main")
+    b, _ = _util.oracle_render(newton, r, 48, 36, camera="main")
+    assert np.isfinite(a).all() and np.isfinite(b).all() and not np.array_equal(a, b)

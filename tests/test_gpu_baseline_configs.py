@@ -162,11 +162,7 @@ SWITCHES = [
     {"SPT_NO_LDS_GEO": "1", "SPT_NO_STREAM": "1"},                              # the refilling state-machine walkers of trace.h for every ray class
     {"SPT_NO_LDS_GEO": "1", "SPT_STREAM_MASK": "7"},                            # the streaming walker (stream.h) for primary, shadow and extension rays
     {"SPT_NO_LDS_GEO": "1", "SPT_STREAM_MASK": "7", "SPT_STREAM_IFIF": "0", "SPT_STREAM_ROUNDS": "2", "SPT_STREAM_REFILL": "64"},   # while-while
-    {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3"},                               # kind-sorted traversal (wst.h) for shadow and extension rays
-    {"SPT_NO_LDS_GEO": "1", "SPT_WST_MASK": "3", "SPT_REFERENCE_BVH": "1"},
     {"SPT_NO_TAIL_LOOP": "1"},                                                  # fused scenes: one launch per bounce even when few paths are left
-    {"SPT_BEZ_DEFER": "1"},                                                     # patch scenes: (ray, patch) pairs clipped by a kernel of their own
-    {"SPT_BEZ_DEFER": "1", "SPT_STREAM_MASK": "7"},
     {"SPT_NO_PIXEL_CULL": "1"},
     {"SPT_NO_OVERLAP": "1"},
     {"SPT_PRIMARY_CHUNKS": "1"},

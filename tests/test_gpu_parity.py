@@ -602,7 +602,7 @@ def test_newton_iteration_build_of_the_patch_test_matches_oracle(spt, scene_name
     r = spt.PathTracer(max_depth=8, sampler=spt.SAMPLER_RANDOM, spp=12, seed=33)
     w, h = 160, 120
     ref_film, _ = _util.oracle_render(sc, r, w, h, camera=camera, flags=flags)
-    for switches in ({}, {"SPT_STREAM_MASK": "0"}, {"SPT_BEZ_LDS": "1"}, {"SPT_BEZ_DEFER": "1"}):
+    for switches in ({}, {"SPT_STREAM_MASK": "0"}, {"SPT_BEZ_LDS": "1"}):
         for k, v in switches.items():
             monkeypatch.setenv(k, v)
         sc2 = _scene(spt, scene_name) if switches else sc

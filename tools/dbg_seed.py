@@ -36,7 +36,7 @@ for name, flags in (("exhaustive", _util.device_oracle_flags()), ("tree-walking"
     refs[name], _ = _util.oracle_render(sc, r, w, h, flags=flags)
 sc.close()
 SETS = ({}, {"SPT_BEZ_LDS": "1"}, {"SPT_STREAM_MASK": "0"}, {"SPT_STREAM_MASK": "2"}, {"SPT_STREAM_MASK": "4"}, {"SPT_STREAM_MASK": "1"}, {"SPT_STREAM_IFIF": "0"},
-        {"SPT_BEZ_DEFER": "1"}, {"SPT_REFERENCE_BVH": "1"})
+        {"SPT_REFERENCE_BVH": "1"})
 for switches in SETS:
     for k in ("SPT_BEZ_LDS", "SPT_STREAM_MASK", "SPT_NO_STREAM", "SPT_REFERENCE_BVH", "SPT_PRIMARY_CHUNKS", "SPT_NO_LDS_TABLES", "SPT_STREAM_IFIF", "SPT_BEZ_DEFER"):
         os.environ.pop(k, None)

@@ -257,7 +257,10 @@ def run_seed(seed, work):
     shard_count = int(rng.choice([1, 1, 2, 3]))
     strip_rows = int(rng.choice([1, 4, 16]))
     spp_pass = int(rng.integers(0, spp + 1))
-    # FUZZ_SWITCHES=1: a random subset of the library's A/B switches per seed (read at scene creation / render time)
+    # FUZZ_SWITCHES=1: a random subset of the library's A/B switches per seed (read at scene creation / render time).
+    # (SPT_WST_MASK and SPT_BEZ_DEFER belonged to two round-2 experiments that were removed in round 3 - the kind-sorted
+    #  traversal and the deferred patch-pair pipeline; they stay in the list, ignored by the library, so that a seed still
+    #  draws the same scene and the same other switches as when it was recorded)
     switches = {}
     if os.environ.get("FUZZ_SWITCHES"):
         for name, values in (("SPT_NO_FUSED", ["1"]), ("SPT_NO_LDS_TABLES", ["1"]), ("SPT_NO_LDS_GEO", ["1"]), ("SPT_NO_PIXEL_CULL", ["1"]),
