@@ -294,3 +294,106 @@ def test_generated_cube_is_the_reference_cube(tmp_path):
     same = np.abs(a - b) < 1e-5
     assert same.mean() > 0.995      # silhouette / edge samples can fall either side in the last bit: another vertex order rounds differently
     assert np.abs(a - b).mean() < 1e-4
+
+
+# ---------------------------------------------------------------- MIS direct lighting against the form-factor integral
+def test_area_light_mis_equals_the_form_factor_integral(tmp_path):
+    """A pin for the arithmetic no closed-form IMAGE of the shipped scenes reaches (round 3): a black, one-sided emissive quad
+    above a Lambert floor.  With max_depth >= 2 a pixel's expectation is emission-free direct lighting,
+        L(p) = rho / pi * Le * integral over the quad of cos(theta_p) cos(theta_l) / r^2 dA,
+    assembled by the integrator from TWO estimators - the light sample (Triangle::sample, ShapeLight's area-to-solid-angle pdf,
+    pdf_shape_light) and the BSDF sample that happens to hit the quad (emission weighted against pdf_shape_light) - under the
+    power heuristic (pt.rs:129-181, 298-302).  The integral is evaluated in float64 by quadrature; nothing of oracle.cpp is used.
+    Either estimator alone (max_depth 1 = light samples only) must give the same mean: the MIS weights sum to one."""
+    (tmp_path / "plane.obj").write_text(open(os.path.join(_util.SCENES, "models", "plane.obj")).read())
+    # the quad in world coordinates, identity transform (Triangle::pdf is an OBJECT-space density, triangle.rs:224-289), facing down
+    (tmp_path / "quad.obj").write_text("v -0.5 1.5 -0.4\nv 0.5 1.5 -0.4\nv 0.5 1.5 0.4\nv -0.5 1.5 0.4\nvn 0 -1 0\nvt 0 0\nf 1/1/1 2/1/1 3/1/1\nf 1/1/1 3/1/1 4/1/1\n")
+    rho, le = 0.8, 10.0
+    sc = {"cameras": {"type": "perspective", "name": "c", "eye": [0.0, 1.0, 3.0], "forward": [0.0, -0.6, -1.0], "up": [0.0, 1.0, 0.0], "fov": 30.0},
+          "textures": [{"type": "scalar", "name": "w", "value": [rho, rho, rho]}, {"type": "scalar", "name": "k", "value": [0.0, 0.0, 0.0]}],
+          "materials": [{"type": "lambert", "name": "white", "albedo": "w"}, {"type": "lambert", "name": "black", "albedo": "k"}], "mediums": [],
+          "surfaces": [{"name": "glow", "material": "black", "emissive": [le, le, le]}],
+          "primitives": [{"type": "trimesh", "name": "plane", "obj_file": "plane.obj"}, {"type": "trimesh", "name": "quad", "obj_file": "quad.obj"}],
+          "instances": [{"name": "floor", "primitive": "plane", "material": "white", "scale": [4.0, 1.0, 4.0]},
+                        {"name": "lamp", "primitive": "quad", "surface": "glow"}],
+          "lights": []}
+    p = tmp_path / "mis.json"
+    p.write_text(json.dumps(sc))
+    scene = spt.load_scene(str(p))
+    w = h = 24
+    # expected radiance at the pixel centres, float64
+    cam = scene.get_camera(None)
+    eye, fwd, up, right = (np.array(list(v), float) for v in (cam.eye, cam.forward, cam.up, cam.right))
+    j, i = np.mgrid[0:h, 0:w]
+    x = ((i + 0.5) / w - 0.5) * (w / h)
+    y = ((h - j - 1) + 0.5) / h - 0.5
+    d = fwd * cam.half_cot_half_fov + right * x[..., None] + up * y[..., None]
+    t = -eye[1] / d[..., 1]
+    pt = eye + d * t[..., None]                                   # on the floor y = 0
+    assert (t > 0).all() and (np.abs(pt[..., [0, 2]]) < 3.9).all()  # every pixel sees the floor, none sees the lamp
+    qx, qz = np.meshgrid((np.arange(160) + 0.5) / 160 - 0.5, ((np.arange(128) + 0.5) / 128 - 0.5) * 0.8)
+    q = np.stack([qx, np.full_like(qx, 1.5), qz], -1).reshape(-1, 3)
+    da = 1.0 * 0.8 / len(q)
+    v = q[None, None] - pt[:, :, None]                            # (h, w, nq, 3)
+    r2 = (v * v).sum(-1)
+    cos_p = v[..., 1] / np.sqrt(r2)                               # floor normal +y
+    cos_l = v[..., 1] / np.sqrt(r2)                               # lamp normal -y, direction from the lamp = -v
+    want = rho / np.pi * le * (cos_p * cos_l / r2).sum(-1) * da
+    assert 0.05 < want.min() and want.max() < 3.0
+    for depth, spp in ((2, 1024), (8, 512), (1, 1024)):
+        r = spt.PathTracer(max_depth=depth, sampler=spt.SAMPLER_RANDOM, spp=spp, seed=7)
+        film, _ = _util.oracle_render(scene, r, w, h)
+        assert np.allclose(film[..., 0], film[..., 1]) and np.isfinite(film).all()
+        rel = film[..., 0].mean() / want.mean() - 1.0
+        assert abs(rel) < 0.01, (depth, rel)                      # the image mean: ~0.3 % noise at these sample counts
+        blocks = film[..., 0].reshape(4, h // 4, 4, w // 4).mean(axis=(1, 3)) / want.reshape(4, h // 4, 4, w // 4).mean(axis=(1, 3))
+        assert np.abs(blocks - 1.0).max() < 0.04, (depth, blocks)  # and block by block across the penumbra-free gradient
+
+
+def test_point_and_spot_light_closed_forms(tmp_path):
+    """Delta lights over a Lambert floor, max_depth 1: every sample of a pixel returns rho / pi * cos(theta) * strength(w) / r^2 at
+    its own floor point - no noise beyond the sub-pixel position.  Written from src/light/point.rs:23-32 and spot.rs:50-66 (linear
+    falloff of dot(direction, -wi) between cos(outer) and cos(inner), the spot's `direction` used as given, not normalised)."""
+    (tmp_path / "plane.obj").write_text(open(os.path.join(_util.SCENES, "models", "plane.obj")).read())
+    rho = 0.6
+    pos = np.array([0.3, 2.0, -0.2])
+    direction = np.array([0.1, -1.0, 0.05])
+    direction /= np.linalg.norm(direction)
+    inner, outer = 15.0, 40.0
+    for kind in ("point", "spot"):
+        light = {"type": kind, "name": "l", "position": pos.tolist(), "strength": [4.0, 2.0, 1.0]}
+        if kind == "spot":
+            light.update({"direction": direction.tolist(), "inner_angle": inner, "outer_angle": outer})
+        sc = {"cameras": {"type": "perspective", "name": "c", "eye": [0.0, 2.5, 4.0], "forward": [0.0, -0.7, -1.0], "up": [0.0, 1.0, 0.0], "fov": 35.0},
+              "textures": [{"type": "scalar", "name": "w", "value": [rho, rho, rho]}], "materials": [{"type": "lambert", "name": "white", "albedo": "w"}],
+              "mediums": [], "surfaces": [], "primitives": [{"type": "trimesh", "name": "plane", "obj_file": "plane.obj"}],
+              "instances": [{"name": "floor", "primitive": "plane", "material": "white", "scale": [6.0, 1.0, 6.0]}], "lights": [light]}
+        p = tmp_path / ("%s.json" % kind)
+        p.write_text(json.dumps(sc))
+        scene = spt.load_scene(str(p))
+        w = h = 32
+        cam = scene.get_camera(None)
+        eye, fwd, up, right = (np.array(list(v), float) for v in (cam.eye, cam.forward, cam.up, cam.right))
+        j, i = np.mgrid[0:h, 0:w]
+        d = fwd * cam.half_cot_half_fov + right * (((i + 0.5) / w - 0.5) * (w / h))[..., None] + up * (((h - j - 1) + 0.5) / h - 0.5)[..., None]
+        pt = eye + d * (-eye[1] / d[..., 1])[..., None]
+        v = pos - pt
+        r2 = (v * v).sum(-1)
+        wi = v / np.sqrt(r2)[..., None]
+        strength = np.array([4.0, 2.0, 1.0])[None, None] * np.ones_like(r2)[..., None]
+        if kind == "spot":
+            co, ci = np.cos(np.radians(outer)), np.cos(np.radians(inner))
+            atten = np.clip(((-wi) @ direction - co) / max(ci - co, 1e-4), 0.0, 1.0)
+            strength = strength * atten[..., None]
+        want = rho / np.pi * wi[..., 1:2] * strength / r2[..., None]
+        film, _ = _util.oracle_render(scene, spt.PathTracer(max_depth=1, sampler=spt.SAMPLER_RANDOM, spp=64, seed=2), w, h)
+        lit = want[..., 0] > 1e-3
+        if kind == "spot":
+            lit &= atten > 0.3          # the rim of the cone (and the pixels straddling it) are compared through the image mean only
+        assert lit.mean() > (0.9 if kind == "point" else 0.15)
+        # pixel mean over 64 jittered positions vs the centre value: a smooth function, second-order difference only
+        assert np.abs(film[lit] / want[lit] - 1.0).max() < (0.05 if kind == "point" else 0.15), kind
+        assert abs(film[lit].mean() / want[lit].mean() - 1.0) < 0.004, kind
+        assert abs(film.mean() / want.mean() - 1.0) < 0.01, kind
+        if kind == "spot":
+            assert (film[want[..., 0] == 0.0] == 0.0).mean() > 0.9      # outside the cone: black (pixels straddling the edge aside)
