@@ -83,11 +83,11 @@ def valu_block(kernel_class, kernel_symbol_regex, avg_launch_ms, launches_per_st
     clock = VALU_CLOCK_GHZ
     if e.get("GRBM_GUI_ACTIVE_per_launch") and e.get("SQ_BUSY_CYCLES_per_launch"):
         pass   # (the PMC pass's own duration is not the live one; the clock constant above is the measured figure)
-    avg_cost, mix_kernel = None, None
+    avg_cost, mix_kernel, sat = None, None, None
     if mj:
         for name, m in mj["kernels"].items():
             if re.search(kernel_symbol_regex, name):
-                avg_cost, mix_kernel = m["avg_issue_cycles_per_wave_instr"], name
+                avg_cost, mix_kernel, sat = m["avg_issue_cycles_per_wave_instr"], name, m.get("saturation_rate_G_wave_instr_per_s")
                 break
     achieved = instr / (avg_launch_ms * 1e-3) / 1e9
     out = {"kernel": mix_kernel or "k_" + kernel_class, "unit": "G wave-instr/s", "wave_instr_per_launch": round(instr),
@@ -95,10 +95,12 @@ def valu_block(kernel_class, kernel_symbol_regex, avg_launch_ms, launches_per_st
            "peak_vop2_stream": VALU_PEAK_VOP2_G, "frac_of_vop2_stream": round(achieved / VALU_PEAK_VOP2_G, 4),
            "source": "SQ_INSTS_VALU of profiles/%s (rocprofv3 --pmc pass of this command) / the live HIP-event launch time" % vf}
     if avg_cost:
-        peak = N_SIMD * clock / avg_cost
+        peak = sat if sat else N_SIMD * clock / avg_cost
         out.update({"avg_issue_cycles_per_wave_instr": avg_cost, "peak": round(peak, 1), "frac": round(achieved / peak, 4),
-                    "peak_note": "%d SIMDs x %.1f GHz / %.2f cycles: the rate at which THIS kernel's static instruction mix (profiles/%s) "
-                                 "saturates the vector ALU" % (N_SIMD, clock, avg_cost, mf)})
+                    "peak_note": "the rate at which THIS kernel's static instruction mix (profiles/%s: 2- / 4- / 8-cycle classes) saturates the vector "
+                                 "ALU, from the measured chip-wide rates of the classes (950 / 560 / 300 G wave-instr/s, profiles/r03_issue_rate.md)" % mf})
+    if e.get("valu_busy_fraction"):
+        out["valu_busy_pmc"] = round(e["valu_busy_fraction"], 4)   # 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): an upper bound (quad-cycle granularity)
     return out
 
 
@@ -360,7 +362,10 @@ def main():
             "shadow": seg_s * (S_SHADOW + 2 * S_RAD),
             # the extend stage reads the ray of a path record and leaves a hit + the record's index (no copy of the record)
             "extend": ext * S_RAY + (verts - hits0) * S_HIT,
-            "resolve": (hits0 * S_RAD + live // 8 + passes * n_pix * 2 * S_RAD) if live else hits0 * S_RAD + passes * n_pix * 2 * S_RAD,
+            # chunked passes (k_resolve_bits): every slot of a live pixel is read (marked or not), its mask byte per 8 samples, the 4-byte
+            # first_slot word of every pixel and the film read + write of the live pixels; plus k_finish's film read + image write
+            "resolve": (live * S_RAD + live // 8 + passes * (n_pix * 4 + (live // max(renderer.spp, 1)) * 2 * S_RAD) + n_pix * 2 * S_RAD) if live else
+                       hits0 * S_RAD + passes * n_pix * 2 * S_RAD,
         }
         kern = {}
         for k in (0, 6, 1, 2, 3, 4):

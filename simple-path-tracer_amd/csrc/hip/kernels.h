@@ -45,6 +45,9 @@
 #ifndef SPT_W_PRI
 #define SPT_W_PRI 5   // cfg5 primary: 8.6 ms at 4 waves (111 VGPRs), 8.3 at 5 (96, 9 spilled), 9.6 at 6 (80, 28 spilled)
 #endif
+#ifndef SPT_PRIMARY_PIN
+#define SPT_PRIMARY_PIN 1   // k_primary keeps its camera terms in VGPRs instead of (spilled) SGPRs, see the kernel
+#endif
 #include "shading.h"
 #include "stream.h"
 
@@ -112,6 +115,9 @@ struct RenderCtx {
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
     uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
+    uint32_t pack_first;                    // 1: a bounce-0 hit record carries (instance | pass-local sample << 20, image pixel index) in inst_src, so
+                                            // the shade kernel does not recover (pixel, sample) from the slot with three integer divisions (~100
+                                            // cycles each); the host sets it when the scene has < 2^20 instances and a pass <= 4096 samples
     const int2* row_span;                   // per image row: first / last pixel that can see an instance (null: only the rectangle above)
     uint32_t debug_normal;                  // SPT_RENDER_DEBUG_NORMAL: the reference's `debug_normal` feature (pt.rs:113-118)
 };
@@ -268,6 +274,21 @@ __global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI :
     const uint32_t s_begin = kChunked ? chunk * rc.chunk_samples : 0u;
     const uint32_t s_end = live ? (kChunked ? min(s_begin + rc.chunk_samples, rc.pass_samples) : rc.pass_samples) : s_begin;
     uint32_t slot_mask = 0u;     // chunked: the slot bits of the current group of 8 samples (chunk_samples is a multiple of 8)
+#if SPT_PRIMARY_PIN
+    // The kernel needs more wave-uniform values than the 102 SGPRs hold (54 are spilled into VGPR lanes and come back through
+    // v_readlane, a 4-cycle VALU instruction each, inside the sample loop), while 24 VGPRs are free below the 4-wave limit.  The
+    // camera terms every sample multiplies with are therefore kept in VGPRs (a broadcast value in a VGPR is as good an operand
+    // as an SGPR): same values, same operations, fewer spills.
+    // (LDS-resident scenes only: the large-scene instantiations are compiled for 5 waves = 96 VGPRs and have none to spare)
+    auto pin = [](float v) { if (kLds) asm volatile("" : "+v"(v)); return v; };
+    const f3 cam_fwd = mk3(pin(rc.cam.forward.x * rc.cam.half_cot), pin(rc.cam.forward.y * rc.cam.half_cot), pin(rc.cam.forward.z * rc.cam.half_cot));
+    const f3 cam_right = mk3(pin(rc.cam.right.x), pin(rc.cam.right.y), pin(rc.cam.right.z)), cam_up = mk3(pin(rc.cam.up.x), pin(rc.cam.up.y), pin(rc.cam.up.z));
+    const f3 cam_eye = mk3(pin(rc.cam.eye.x), pin(rc.cam.eye.y), pin(rc.cam.eye.z)), bs_oc = mk3(pin(rc.bs_oc.x), pin(rc.bs_oc.y), pin(rc.bs_oc.z));
+    const float bs_c = pin(rc.bs_c), width_inv = pin(rc.width_inv), height_inv = pin(rc.height_inv), aspect = pin(rc.aspect);
+#else
+    const f3 cam_fwd = rc.cam.forward * rc.cam.half_cot, cam_right = rc.cam.right, cam_up = rc.cam.up, cam_eye = rc.cam.eye, bs_oc = rc.bs_oc;
+    const float bs_c = rc.bs_c, width_inv = rc.width_inv, height_inv = rc.height_inv, aspect = rc.aspect;
+#endif
     for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t gs = rc.pass_first + s;
         DRng rng;
@@ -275,20 +296,20 @@ __global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI :
         if (!lazy_rng) rng.s = spt_rng_seed(rc.seed, pixel, gs);
         float ox, oy;
         pixel_offset(rc, pixel, gs, rng, &ox, &oy);
-        float x = (((float)i + ox) * rc.width_inv - 0.5f) * rc.aspect;           // pt.rs:269
-        float y = ((float)(rc.height - j - 1u) + oy) * rc.height_inv - 0.5f;       // pt.rs:270-271
+        float x = (((float)i + ox) * width_inv - 0.5f) * aspect;           // pt.rs:269
+        float y = ((float)(rc.height - j - 1u) + oy) * height_inv - 0.5f;       // pt.rs:270-271
         // PerspectiveCamera::generate_ray (camera/perspective.rs:40-47), split so that a sample whose
         // un-normalised direction already misses the bounding sphere of the whole scene skips the
         // normalisation and the traversal: nothing can be hit, and without an environment the sample
         // is black.  The sphere is inflated, so the test only removes rays every box test would reject.
-        const f3 du = (rc.cam.forward * rc.cam.half_cot + rc.cam.right * x) + rc.cam.up * y;
+        const f3 du = (cam_fwd + cam_right * x) + cam_up * y;
         bool may_hit = valid && in_bounds;
-        if (may_hit && rc.bs_valid && rc.bs_c > 0.0f) {
-            const float b = dot(du, rc.bs_oc);
-            may_hit = valid && (b > 0.0f) && (b * b >= dot(du, du) * rc.bs_c);
+        if (may_hit && rc.bs_valid && bs_c > 0.0f) {
+            const float b = dot(du, bs_oc);
+            may_hit = valid && (b > 0.0f) && (b * b >= dot(du, du) * bs_c);
         }
         DRay ray;
-        ray.o = rc.cam.eye;
+        ray.o = cam_eye;
         ray.t_min = kTMinEps;
         ray.d = du;
         if (may_hit || has_env) ray.d = normalize(du);
@@ -331,7 +352,7 @@ __global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI :
             // rebuilds, so only (direction, slot) and the hit record travel: 36 B instead of 92 B per hit
             rc.qa.d_pdf[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float((uint32_t)ri));
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
-            rc.hits.inst_src[slot] = make_uint2((uint32_t)h.inst, slot);
+            rc.hits.inst_src[slot] = rc.pack_first ? make_uint2((uint32_t)h.inst | (s << 20), pixel) : make_uint2((uint32_t)h.inst, slot);
         }
     }
     if (kCount) flush_visits(rc, vc, 0u);
@@ -479,15 +500,25 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
                 // rebuild the constants of a camera path from the slot (see k_primary)
                 const float4 b = kPrefetch ? cur_b : rc.qa.d_pdf[idx];
                 slot = __float_as_uint(b.w);
-                const uint32_t s_local = slot / rc.n_pixels, lp = slot - s_local * rc.n_pixels;
-                const uint32_t row_local = lp / rc.width, col = lp - row_local * rc.width;
-                const uint32_t j = global_row(rc, row_local);
-                rng.s = spt_rng_seed(rc.seed, j * rc.width + col, rc.pass_first + s_local);
+                uint32_t s_local, pix, j = 0u, col = 0u;
+                if (rc.pack_first) {   // (wave-uniform) the record says which pixel and which sample it is
+                    s_local = cur_is.x >> 20;
+                    pix = cur_is.y;
+                    if (kTex) { j = pix / rc.width; col = pix - j * rc.width; }
+                } else {
+                    s_local = slot / rc.n_pixels;
+                    const uint32_t lp = slot - s_local * rc.n_pixels;
+                    const uint32_t row_local = lp / rc.width;
+                    col = lp - row_local * rc.width;
+                    j = global_row(rc, row_local);
+                    pix = j * rc.width + col;
+                }
+                rng.s = spt_rng_seed(rc.seed, pix, rc.pass_first + s_local);
                 if (kTex) {
                     // the auxiliary rays of generate_ray_with_aux_ray (camera/mod.rs:15-21, offsets of pt.rs:272-275)
                     // are a function of the pixel offsets: redo the sampler draw instead of carrying 12 floats
                     float ox, oy;
-                    pixel_offset(rc, j * rc.width + col, rc.pass_first + s_local, rng, &ox, &oy);
+                    pixel_offset(rc, pix, rc.pass_first + s_local, rng, &ox, &oy);
                     float x = (((float)col + ox) * rc.width_inv - 0.5f) * rc.aspect;
                     float y = ((float)(rc.height - j - 1u) + oy) * rc.height_inv - 0.5f;
                     aux_xd = normalize((rc.cam.forward * rc.cam.half_cot + rc.cam.right * (x + rc.aux_dx)) + rc.cam.up * y);
@@ -525,7 +556,7 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
             }
             DHit h;
             h.t = hv.x; h.v = hv.y; h.w = hv.z; h.prim = __float_as_int(hv.w);
-            h.inst = (int32_t)cur_is.x;
+            h.inst = (kFirst && rc.pack_first) ? (int32_t)(cur_is.x & 0xfffffu) : (int32_t)cur_is.x;
             if (kLoop && carried) h = c_h;
             const bool does_hit = h.inst >= 0;
             bool alive = true;       // false: path ended without the RR / depth tail (`break`)
@@ -1190,7 +1221,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
         if (hit) {
             rc.qa.d_pdf[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)ri));
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
-            rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, slot);
+            rc.hits.inst_src[slot] = rc.pack_first ? make_uint2((uint32_t)wk.h.inst | (s_cur << 20), pixel) : make_uint2((uint32_t)wk.h.inst, slot);
         }
         if (retire) busy = false;
     }

@@ -1635,6 +1635,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                 rc.pass_first = s0;
                 rc.pass_samples = std::min(spp_pass, p.spp - s0);
                 rc.rad_plane = collect ? (size_t)p.spp * n_pix : (size_t)rc.pass_samples * n_pix;
+                rc.pack_first = (sc->d.n_instances < (1u << 20) && rc.pass_samples <= 4096u && std::getenv("SPT_NO_PACK_FIRST") == nullptr) ? 1u : 0u;
                 rc.rad = sc->rad.as<float>() + (collect ? (size_t)s0 * n_pix : 0);
                 begin(SPT_K_OTHER);
                 HIP_CHECK(hipMemsetAsync(rc.counts, 0, counts_bytes, st));

@@ -75,10 +75,13 @@ def main():
             n[cost(o)] += 1
         tot = max(len(valu), 1)
         avg = (2 * n[2] + 4 * n[4] + 8 * n[8]) / tot
+        # the rate at which this mix saturates the vector ALU, from the MEASURED chip-wide rates of the three classes (G wave-instr/s:
+        # 950 / 560 / 300, profiles/r03_issue_rate.md) - no clock assumption: 1 / rate = sum over classes of share / class rate
+        sat = tot / (n[2] / 950.0 + n[4] / 560.0 + n[8] / 300.0)
         res[name] = {"valu_instructions_static": len(valu), "class_2_cycles": n[2], "class_4_cycles": n[4], "class_8_cycles": n[8],
-                     "avg_issue_cycles_per_wave_instr": round(avg, 3), "salu_static": sum(o.startswith("s_") for o in ops),
-                     "lds_static": sum(o.startswith("ds_") for o in ops)}
-        print("%-90s valu %5d  (2 cyc %5d, 4 cyc %5d, 8 cyc %4d)  avg %.2f cycles / wave-instr" % (name[:90], len(valu), n[2], n[4], n[8], avg))
+                     "avg_issue_cycles_per_wave_instr": round(avg, 3), "saturation_rate_G_wave_instr_per_s": round(sat, 1),
+                     "salu_static": sum(o.startswith("s_") for o in ops), "lds_static": sum(o.startswith("ds_") for o in ops)}
+        print("%-90s valu %5d  (2 cyc %5d, 4 cyc %5d, 8 cyc %4d)  avg %.2f cycles / wave-instr, saturates at %.0f G wave-instr/s" % (name[:90], len(valu), n[2], n[4], n[8], avg, sat))
     if out:
         json.dump({"lib": os.path.basename(lib), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 
