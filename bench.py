@@ -551,7 +551,10 @@ def other_configs(spt, device, only=""):
         fetch_gbs = alg[dom] / (kms[dom] * 1e-3) / 1e9
         if hbm is not None:
             gbs = hbm / (kms[dom] * 1e-3) / 1e9
-            entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "limited_by": "dependent-fetch latency / divergent address processing (DESIGN.md section 6)",
+            limited = {"shade": "VALU issue at ~0.36 lane utilisation: the vertices of bounce >= 1 arrive in an order that splits every wave over the kernel's branches (DESIGN.md section 6)",
+                       "shade_first": "VALU issue (0.69 lane utilisation)"}.get(dom, "divergent traversal: instruction issue for half-empty waves (node step / triangle leaf / instance entry in turn) "
+                                                                                     "and dependent fetches served by L2 / Infinity Cache (DESIGN.md section 6)")
+            entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "limited_by": limited,
                                  "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "hbm_MB": round(hbm / 1e6, 1), "ms": round(kms[dom], 2),
                                  "source": "FETCH_SIZE x 2 + WRITE_SIZE per dispatch (profiles/%s) x %d launches of this run" % (pf, launches),
