@@ -115,6 +115,7 @@ struct RenderCtx {
     uint32_t dyn_refill_below, dyn_steps;   // tuning of the refilling kernels
     uint32_t stream_rounds, stream_refill_below;   // streaming kernels: while-while rounds between two retire / refill checks; refill threshold
     unsigned long long* visits;             // SPT_RENDER_COUNT_VISITS: [nodes, triangles, instances] fetched by the traversals (kCount kernels)
+    uint32_t n_classes, class_cap;          // hit queue of bounce >= 1: sub-queues per shard (1: one queue, the fused pipeline) and their distance
     uint32_t pack_first;                    // 1: a bounce-0 hit record carries (instance | pass-local sample << 20, image pixel index) in inst_src, so
                                             // the shade kernel does not recover (pixel, sample) from the slot with three integer divisions (~100
                                             // cycles each); the host sets it when the scene has < 2^20 instances and a pass <= 4096 samples
@@ -136,7 +137,15 @@ SPT_DEV uint32_t global_row(const RenderCtx& rc, uint32_t row_local) {
 //    multiple of 8 a shard is written and later read by blocks of ONE XCD and its
 //    records stay in that XCD's 4 MiB L2 between stages (speed only, never correctness).
 constexpr uint32_t kShards = 64;
-enum { Q_HIT = 0, Q_SHADOW = 1, Q_EXT = 2, Q_SHADOW_CURSOR = 3, Q_EXT_CURSOR = 4, Q_KINDS = 5 };
+// The hit queue of bounce >= 1 is kClasses sub-queues per shard when the scene is shaded by the general kernels (round 3): the
+// extension stage files a vertex under the BxDF class of the instance it hit (DScene::inst_class; kClasses - 1 = the path travels
+// inside a medium: a medium event first, whatever it hit), the shade stage consumes class after class, so that the 64 vertices of a wave run ONE branch of mat_sample / mat_eval /
+// mat_pdf and agree on whether there is a light sample at all.  Measured motive (tools/shade_coherence_probe.py, cfg4): the same
+// kernel runs at 0.36 lane utilisation on the mixed queue and at 0.81 when every instance has the same material.  Class 0 keeps the
+// old indices (shard * shard_cap + i), class c lives class_cap = kShards * shard_cap entries further per class.
+constexpr uint32_t kClasses = 8;
+enum { Q_HIT = 0, Q_SHADOW = 1, Q_EXT = 2, Q_SHADOW_CURSOR = 3, Q_EXT_CURSOR = 4, Q_HIT_CLASS1 = 5, Q_KINDS = 5 + (kClasses - 1) };
+SPT_DEV uint32_t q_hit_kind(uint32_t cls) { return cls == 0u ? (uint32_t)Q_HIT : (uint32_t)Q_HIT_CLASS1 + cls - 1u; }
 SPT_DEV uint32_t* q_count(const uint32_t* counts, uint32_t bounce, uint32_t q, uint32_t shard) {
     return const_cast<uint32_t*>(counts) + ((size_t)(bounce * Q_KINDS + q) * kShards + shard) * 32u;
 }
@@ -214,6 +223,24 @@ SPT_DEV void flush_visits(const RenderCtx& rc, const LaneVisits& vc, uint32_t cl
         for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
         if (lane_id() == 0u && t) atomicAdd(rc.visits + 3u * cls + k, t);
     }
+}
+
+// Append a kept vertex (the closest hit of an extension ray, or an in-medium miss: inst < 0) to the hit queue of bounce `bounce_next`:
+// one wave-aggregated append per class present in the wave (usually 1 - 3).  Returns the lane's queue index (valid where keep).
+SPT_DEV uint32_t hit_push(const DScene& sc, const RenderCtx& rc, bool keep, int32_t inst, uint32_t bounce_next, uint32_t shard) {
+    if (rc.n_classes <= 1u) return shard * rc.shard_cap + wave_push(keep, q_count(rc.counts, bounce_next, Q_HIT, shard));
+    const uint32_t cls = keep ? (inst >= 0 ? (uint32_t)sc.inst_class[inst] : kClasses - 1u) : 0xffffffffu;
+    uint32_t slot = 0u;
+    unsigned long long todo = __ballot(keep);
+    while (todo != 0ull) {       // wave-uniform: every pass retires all lanes of one class
+        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t c = (uint32_t)__shfl((int)cls, (int)leader, 64);
+        const bool mine = keep && cls == c;
+        const uint32_t pos = wave_push(mine, q_count(rc.counts, bounce_next, q_hit_kind(c), shard));
+        if (mine) slot = c * rc.class_cap + shard * rc.shard_cap + pos;
+        todo &= ~__ballot(mine);
+    }
+    return slot;
 }
 
 SPT_DEV uint32_t pack_meta(uint32_t depth, int32_t medium) { return depth | ((uint32_t)(medium + 1) << 8); }
@@ -345,7 +372,9 @@ __global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI :
         // (deferring this append by one iteration to overlap the counter atomic with the next sample was tried
         //  twice: at 120 VGPRs the pending state cost a wave per SIMD and it was slower, at 104 VGPRs it fits
         //  but MEASURED the same 2.70 ms - the atomic is not what the kernel waits for)
-        const uint32_t slot = shard * rc.shard_cap + wave_push(hit, hit_counter);
+        // (general pipeline: camera hits are filed by BxDF class too, see kClasses - object boundaries inside a wave cost the bounce-0
+        //  shade kernel a third of its lanes; the compact record below sits at the hit's own index, so qa.d_pdf spans all classes)
+        const uint32_t slot = rc.n_classes > 1u ? hit_push(sc, rc, hit, h.inst, 0u, shard) : shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {
             // bounce-0 records are compact: origin (eye), t_min, throughput (1), last_pdf (0), depth, medium and
             // the RNG stream (a function of pixel and sample = of the slot) are constants that k_shade<.., true>
@@ -422,10 +451,13 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
     // kFeat 3: Subsurface substrates (the probe), 4: position-normal distributions (the glint walks), 5: both
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3 || kFeat == 5, kPndf = kFeat == 4 || kFeat == 5;
     const uint32_t shard = blockIdx.x % kShards;
-    const uint32_t n = *q_count(rc.counts, bounce, Q_HIT, shard);
+    // classes of the hit queue this launch consumes (the fused pipeline has one)
+    const uint32_t n_cls = kFused ? 1u : rc.n_classes;
+    uint32_t n_any = 0u;
+    for (uint32_t c = 0; c < n_cls; ++c) n_any = max(n_any, *q_count(rc.counts, bounce, q_hit_kind(c), shard));
     // workgroups of an empty shard (most of them in the late bounces) leave before staging anything into LDS;
     // a workgroup whose first item is past the end has nothing to do either (block-uniform, no barrier skipped)
-    if ((blockIdx.x / kShards) * blockDim.x >= n) return;
+    if ((blockIdx.x / kShards) * blockDim.x >= n_any) return;
     if (kFused || kTab || kGeoLds) stage_geometry<true>(sc);
     uint32_t* shadow_count = q_count(rc.counts, bounce, Q_SHADOW, shard);
     uint32_t* ext_count = q_count(rc.counts, bounce, Q_EXT, shard);
@@ -437,20 +469,23 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
     // + the rest of the 72-byte path record: 14 more (k_shade<1> would reach 260 VGPRs = 1 wave / SIMD).  Fused kernels only:
     // there the record sits at the hit's own index; un-fused it is behind the hit's source index (see HitQueue)
     constexpr bool kPrefetchPath = !kFirst && kSimple && kFused;
+    const uint32_t i_first = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u);
+    for (uint32_t cls = 0; cls < n_cls; ++cls) {
+    const uint32_t n = *q_count(rc.counts, bounce, q_hit_kind(cls), shard);
+    const uint32_t hbase = cls * rc.class_cap + qbase;      // (class 0: the old indices, where bounce 0 and the fused kernels keep records and hits aligned)
     float4 pre_hv = make_float4(0, 0, 0, 0), pre_b = make_float4(0, 0, 0, 0);
     float4 pre_a = pre_hv, pre_c = pre_hv, pre_d = pre_hv;
     uint2 pre_rs = make_uint2(0u, 0u);
     uint2 pre_is = make_uint2(0xffffffffu, 0u);
-    const uint32_t i_first = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u);
     if (kPrefetch && i_first + lane_id() < n) {
-        const uint32_t k = qbase + i_first + lane_id();
+        const uint32_t k = hbase + i_first + lane_id();
         pre_hv = rc.hits.t_v_w_prim[k]; pre_is = rc.hits.inst_src[k];
         if (kFirst || kFused) pre_b = rc.qa.d_pdf[k];
         if (kPrefetchPath) { pre_a = rc.qa.o_tmin[k]; pre_c = rc.qa.thr_slot[k]; pre_d = rc.qa.lsi_meta[k]; pre_rs = rc.qa.rng[k]; }
     }
     for (uint32_t i0 = i_first; i0 < n; i0 += stride) {
         const bool active = i0 + lane_id() < n;
-        const uint32_t idx = qbase + i0 + lane_id();
+        const uint32_t idx = hbase + i0 + lane_id();
         const float4 cur_hv = pre_hv, cur_b = pre_b, cur_a = pre_a, cur_c = pre_c, cur_d = pre_d;
         const uint2 cur_rs = pre_rs;
         const uint2 cur_is = pre_is;
@@ -819,6 +854,7 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
         uint32_t es = qbase + wave_push_finish(pe);
         if (want_ext) store_path(rc.qb, es, next_ray, next_pdf, thr, slot, lsi, pack_meta(depth, medium), rng);
     }
+    }   // classes
 }
 
 // ---------------------------------------------------------------------------- shadow
@@ -849,13 +885,12 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L 
     if ((blockIdx.x / kShards) * blockDim.x >= n) return;   // nothing for this workgroup: skip the LDS staging too
     stage_geometry<kLds>(sc);
     LaneVisits vc{0u, 0u, 0u};
-    uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
     for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
         const bool active = i0 + lane_id() < n;
         const uint32_t idx = qbase + i0 + lane_id();
-        bool keep = false;
+        bool keep = false, in_medium = false;
         DHit h;
         h.inst = -1; h.t = SPT_F32_MAX; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
         if (active) {
@@ -864,7 +899,7 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L 
             DRay r;
             r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
             h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
-            const bool in_medium = (meta >> 8) != 0u;
+            in_medium = (meta >> 8) != 0u;
             if (h.inst >= 0 || in_medium) {
                 keep = true;
             } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
@@ -877,7 +912,7 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L 
             }
         }
         // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        uint32_t slot = qbase + wave_push(keep, next_count);
+        const uint32_t slot = hit_push(sc, rc, keep, h.inst, bounce + 1u, shard);
         if (keep) {
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
             rc.hits.inst_src[slot] = make_uint2((uint32_t)h.inst, idx);
@@ -963,7 +998,6 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
     uint32_t* cursor = q_count(rc.counts, bounce, Q_EXT_CURSOR, shard);
-    uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     uint2 spill_mem[kSpillStack];
     Walker<false, true, kCount> wk;
@@ -1004,7 +1038,7 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
             busy = false;
         }
         // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        const uint32_t slot = qbase + wave_push(keep, next_count);
+        const uint32_t slot = hit_push(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
         if (keep) {
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
             rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
@@ -1066,7 +1100,6 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
     uint32_t* cursor = q_count(rc.counts, bounce, Q_EXT_CURSOR, shard);
-    uint32_t* next_count = q_count(rc.counts, bounce + 1, Q_HIT, shard);
     const uint32_t qbase = shard * rc.shard_cap;
     uint2 spill_mem[kSpillStack];
     SWalker<true, kCount> wk;
@@ -1109,7 +1142,7 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
             busy = false;
         }
         // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        const uint32_t slot = qbase + wave_push(keep, next_count);
+        const uint32_t slot = hit_push(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
         if (keep) {
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
             rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
@@ -1217,7 +1250,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
                 slot_mask = 0u;
             }
         }
-        const uint32_t slot = shard * rc.shard_cap + wave_push(hit, hit_counter);
+        const uint32_t slot = rc.n_classes > 1u ? hit_push(sc, rc, hit, wk.h.inst, 0u, shard) : shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {
             rc.qa.d_pdf[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)ri));
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));

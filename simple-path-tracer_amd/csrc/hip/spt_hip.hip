@@ -529,7 +529,7 @@ struct spt_scene {
     size_t lds_bytes = 0;   // dynamic LDS per 256-thread block: traversal stack (+ geometry)
     // render workspace (grown on demand, reused between calls)
     DeviceBuffer qa[5], qb[5], hit_f4, hit_inst, hit_f4_next, hit_inst_next, sh[3], counts, rad, film, first_slot, slot_bits, out;
-    DeviceBuffer trace_in, trace_out, visits;
+    DeviceBuffer trace_in, trace_out, visits, inst_class;
     std::mutex mu;
     double bs_center[3] = {0, 0, 0}, bs_radius = 0;  // bounding sphere of all instance boxes
     double world_lo[3] = {0, 0, 0}, world_hi[3] = {0, 0, 0};   // their union
@@ -1204,6 +1204,33 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             d.recipes = sc->recipes.as<uint4>();
         }
         sc->simple = simple;
+        {   // the class a hit on each instance is queued under for the shade stage of bounce >= 1 (kernels.h, kClasses): by the code
+            // path its material takes through mat_sample / mat_eval / mat_pdf and by whether it has a light sample at all
+            std::vector<uint8_t> cls(std::max<uint32_t>(s.n_instances, 1u), 0);
+            for (uint32_t i = 0; i < s.n_instances; ++i) {
+                const spt_material& m = s.materials[s.surfaces[s.instances[i].surface].material];
+                uint32_t b = m.bxdf;
+                if (m.recipe != 0u) {      // evaluated per hit: the kind the recipe usually resolves to
+                    switch (s.material_recipes[m.recipe - 1u].type) {
+                    case SPT_MAT_LAMBERT: b = SPT_BXDF_LAMBERT; break;
+                    case SPT_MAT_CONDUCTOR: b = SPT_BXDF_MICROFACET_CONDUCTOR; break;
+                    case SPT_MAT_DIELECTRIC: b = SPT_BXDF_MICROFACET_DIELECTRIC; break;
+                    default: b = SPT_BXDF_MICROFACET_PLASTIC; break;
+                    }
+                }
+                switch (b) {
+                case SPT_BXDF_LAMBERT: cls[i] = 0; break;
+                case SPT_BXDF_MICROFACET_CONDUCTOR: cls[i] = 1; break;
+                case SPT_BXDF_SPECULAR_CONDUCTOR: cls[i] = 2; break;
+                case SPT_BXDF_MICROFACET_DIELECTRIC: cls[i] = 3; break;
+                case SPT_BXDF_SPECULAR_DIELECTRIC: cls[i] = 4; break;
+                case SPT_BXDF_PSEUDO: cls[i] = 5; break;
+                default: cls[i] = 6; break;       // the plastic / PBR lobes, glints
+                }
+            }
+            sc->inst_class.upload(cls.data(), cls.size());
+            d.inst_class = sc->inst_class.as<uint8_t>();
+        }
         if (s.n_instances) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             bool finite = true;
@@ -1491,11 +1518,15 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             // collect: every sample of the window is kept (wide box filter), else only the samples of one pass
             const uint64_t rad64 = (uint64_t)n_pix * (collect ? p.spp : spp_pass);
 
-            for (int k = 0; k < 4; ++k) { sc->qa[k].ensure(cap * 16); sc->qb[k].ensure(cap * 16); }
+            // the hit queue is binned by BxDF class for the general shade kernels (kernels.h, kClasses): class c lives c * cap
+            // entries further.  Memory is what MI355X has (24 B x cap x 8 classes = 26 GB for a 128 M-sample pass)
+            const bool fused_here = sc->fused && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
+            const uint32_t n_classes = (!fused_here && p.max_depth > 1 && cap * (uint64_t)kClasses <= 0xffffffffull && std::getenv("SPT_NO_CLASS_QUEUES") == nullptr) ? kClasses : 1u;
+            for (int k = 0; k < 4; ++k) { sc->qa[k].ensure(cap * 16 * (k == 1 ? n_classes : 1u)); sc->qb[k].ensure(cap * 16); }   // (qa[1]: the compact bounce-0 records sit at their hit's index, in every class)
             sc->qa[4].ensure(cap * 8);
             sc->qb[4].ensure(cap * 8);
-            sc->hit_f4.ensure(cap * 16);
-            sc->hit_inst.ensure(cap * 8);
+            sc->hit_f4.ensure(cap * 16 * n_classes);
+            sc->hit_inst.ensure(cap * 8 * n_classes);
             // see k_shade<.., kFused>.  Only the lean k_shade<0> variant gains: with the general kernel's 220+ VGPRs
             // the two traversals run at 2 waves / SIMD and cfg4 is faster un-fused (4.30 vs 4.00 Gsamples/s, measured)
             const bool fused = sc->fused && sc->simple && std::getenv("SPT_NO_FUSED") == nullptr;
@@ -1533,6 +1564,8 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             rc.shadow = ShadowQueue{sc->sh[0].as<float4>(), sc->sh[1].as<float4>(), sc->sh[2].as<float4>()};
             rc.counts = sc->counts.as<uint32_t>();
             rc.shard_cap = (uint32_t)shard_cap64;
+            rc.n_classes = n_classes;
+            rc.class_cap = (uint32_t)cap;
             rc.rad = sc->rad.as<float>();
             rc.film = sc->film.as<float>();
             rc.first_slot = sc->first_slot.as<uint32_t>();
@@ -1767,6 +1800,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     auto qsum = [&](uint32_t b, uint32_t q) {
                         uint64_t t = 0;
                         for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * Q_KINDS + q) * kShards + s) * 32];
+                        if (q == Q_HIT)     // the hit queue's other classes (bounce >= 1 of the general pipeline)
+                            for (uint32_t c = 1; c < kClasses; ++c)
+                                for (uint32_t s = 0; s < kShards; ++s) t += h_counts[((size_t)(b * Q_KINDS + Q_HIT_CLASS1 + c - 1u) * kShards + s) * 32];
                         return t;
                     };
                     if (p.max_depth > 1) sc->tail_vertices = qsum(1, Q_HIT);

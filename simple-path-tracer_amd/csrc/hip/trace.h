@@ -76,6 +76,7 @@ struct DScene {
     const spt_pndf_node* pndf_nodes;
     const uint32_t* pndf_refs;
     const uint32_t* pndf_roots;
+    const uint8_t* inst_class;     // per instance: the class the hit queue of bounce >= 1 files its hits under (kernels.h, kClasses)
 };
 
 struct DHit {

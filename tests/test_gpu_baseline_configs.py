@@ -169,6 +169,11 @@ SWITCHES = [
     {"SPT_PRIMARY_CHUNKS": "5"},
     {"SPT_BVH_MAX_LEAF": "2"},
     {"SPT_BOX_BAND_BYTES": "200000"},
+    {"SPT_NO_CLASS_QUEUES": "1"},                                               # one hit queue per shard instead of one per BxDF class
+    {"SPT_NO_FUSED": "1", "SPT_NO_CLASS_QUEUES": "1"},
+    {"SPT_NO_PACK_FIRST": "1"},                                                 # bounce-0 records as (slot) instead of (instance | sample, pixel)
+    {"SPT_NO_ROW_SPANS": "1"},                                                  # no per-row screen-space spans in k_primary
+    {"SPT_RESOLVE_BATCH": "32"},
 ]
 ALL_SWITCHES = sorted({k for s in SWITCHES for k in s})
 
