@@ -11,7 +11,11 @@ LIBDIR   := $(PKG)/lib
 CXX      ?= g++
 HIPCC    ?= hipcc
 CXXFLAGS := -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -fno-fast-math -Iinclude
-HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar f32 operations into v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a packed
+# f32 instruction issues in 4 cycles per wave64 (profiles/r03_issue_rate.md) - no better than two 2-cycle VOP2s - and every
+# pair costs v_mov / v_pk_mov shuffles to line its operands up.  MEASURED (round 3): cfg2 81.3 -> 88.8 Gsamples/s, cfg4
+# 91.9 -> 88.2 ms, cfg5 143.3 -> 138.6 ms, same bits (packed and scalar IEEE operations round alike).
+HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -Wall -Wno-unused-function -Iinclude
 
 HOST_SRC := $(wildcard $(PKG)/csrc/host/*.cpp)

@@ -150,10 +150,14 @@ template <bool kLds>
 __global__ void __launch_bounds__(256) k_trace_closest(DScene sc, uint32_t n, const spt_ray* rays, spt_hit* hits) {
     stage_geometry<kLds>(sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool active = i < n;
+    const spt_ray in = rays[active ? i : 0u];
     DRay r;
-    r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
-    DHit h = trace_closest<kLds>(sc, r, rays[i].t_max);
+    r.o = mk3(in.o); r.d = mk3(in.d); r.t_min = in.t_min;
+    DHit h;
+    if (kLds && sc.flat) h = flat_closest(sc, r, in.t_max, active);   // (whole waves, see flat.h)
+    if (!active) return;
+    if (!(kLds && sc.flat)) h = trace_closest<kLds>(sc, r, in.t_max);
     const bool hit = h.inst >= 0;
     hits[i].t = hit ? h.t : SPT_F32_MAX;
     hits[i].instance = h.inst;
@@ -165,10 +169,15 @@ template <bool kLds>
 __global__ void __launch_bounds__(256) k_trace_any(DScene sc, uint32_t n, const spt_ray* rays, uint8_t* occluded) {
     stage_geometry<kLds>(sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool active = i < n;
+    const spt_ray in = rays[active ? i : 0u];
     DRay r;
-    r.o = mk3(rays[i].o); r.d = mk3(rays[i].d); r.t_min = rays[i].t_min;
-    occluded[i] = trace_any<kLds>(sc, r, rays[i].t_max) ? 1 : 0;
+    r.o = mk3(in.o); r.d = mk3(in.d); r.t_min = in.t_min;
+    bool occ = false;
+    if (kLds && sc.flat) occ = flat_any(sc, r, in.t_max, active);
+    if (!active) return;
+    if (!(kLds && sc.flat)) occ = trace_any<kLds>(sc, r, in.t_max);
+    occluded[i] = occ ? 1 : 0;
 }
 
 // the same seams through the streaming walker (scenes that do not fit LDS): one ray per lane, no refill

@@ -21,12 +21,14 @@
     X((k_primary<false, false, true>), SPT_ARGS_PRIMARY)  \
     X((k_primary<false, true, true>), SPT_ARGS_PRIMARY)
 
-// k_shadow / k_extend <kLds, kCount>, refilling variants <kCount>
+// k_shadow / k_extend <kLds, kCount, kFlat>, refilling variants <kCount>
 #define SPT_KERNELS_RAYS(X)                          \
     X((k_shadow<true, false>), SPT_ARGS_BOUNCE)      \
+    X((k_shadow<true, false, true>), SPT_ARGS_BOUNCE) \
     X((k_shadow<false, false>), SPT_ARGS_BOUNCE)     \
     X((k_shadow<false, true>), SPT_ARGS_BOUNCE)      \
     X((k_extend<true, false>), SPT_ARGS_BOUNCE)      \
+    X((k_extend<true, false, true>), SPT_ARGS_BOUNCE) \
     X((k_extend<false, false>), SPT_ARGS_BOUNCE)     \
     X((k_extend<false, true>), SPT_ARGS_BOUNCE)      \
     X((k_shadow_dyn<false>), SPT_ARGS_BOUNCE)        \

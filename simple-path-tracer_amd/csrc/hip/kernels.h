@@ -50,6 +50,7 @@
 #endif
 #include "shading.h"
 #include "stream.h"
+#include "flat.h"
 
 
 struct DCamera {
@@ -858,7 +859,8 @@ __global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SH
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool kLds, bool kCount = false>
+// kFlat (with kLds, kCount off): the exhaustive loops of flat.h instead of the tree walk
+template <bool kLds, bool kCount = false, bool kFlat = false>
 __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_SHD_L : 1) k_shadow(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_SHADOW, shard);
@@ -867,6 +869,21 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_SHD_L 
     LaneVisits vc{0u, 0u, 0u};
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
+    if (kFlat) {   // flat.h wants whole waves: a uniform loop, `active` marks the lanes that carry a ray
+        for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+            const bool active = i0 + lane_id() < n;
+            const uint32_t idx = qbase + (active ? i0 + lane_id() : 0u);
+            const float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx];
+            DRay r;
+            r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+            const bool occluded = flat_any(sc, r, b.w, active);
+            if (active && !occluded) {
+                const float4 c = rc.shadow.contrib_slot[idx];
+                rad_add(rc, __float_as_uint(c.w), mk3(c));
+            }
+        }
+        return;
+    }
     for (uint32_t i = (blockIdx.x / kShards) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t idx = qbase + i;
         float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx], c = rc.shadow.contrib_slot[idx];
@@ -878,7 +895,7 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_SHD_L 
 }
 
 // ---------------------------------------------------------------------------- extend
-template <bool kLds, bool kCount = false>
+template <bool kLds, bool kCount = false, bool kFlat = false>
 __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L : 1) k_extend(DScene sc, RenderCtx rc, uint32_t bounce) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = *q_count(rc.counts, bounce, Q_EXT, shard);
@@ -893,12 +910,19 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L 
         bool keep = false, in_medium = false;
         DHit h;
         h.inst = -1; h.t = SPT_F32_MAX; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
+        if (kFlat) {   // flat.h wants whole waves (inactive lanes read entry 0 of the shard and discard what they find)
+            const float4 a = rc.qb.o_tmin[active ? idx : qbase];
+            const float4 b = rc.qb.d_pdf[active ? idx : qbase];
+            DRay r;
+            r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+            h = flat_closest(sc, r, SPT_F32_MAX, active);
+        }
         if (active) {
             const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
             const uint32_t meta = __float_as_uint(rc.qb.lsi_meta[idx].w);
             DRay r;
             r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-            h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
+            if (!kFlat) h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
             in_medium = (meta >> 8) != 0u;
             if (h.inst >= 0 || in_medium) {
                 keep = true;

@@ -1000,7 +1000,12 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                     float rf;
                     std::memcpy(&rf, &root_ref, 4);
                     mesh_rec[2 * i] = make_float4(rn.bmin[0], rn.bmin[1], rn.bmin[2], rf);
-                    mesh_rec[2 * i + 1] = make_float4(rn.bmax[0], rn.bmax[1], rn.bmax[2], 0.0f);
+                    // (flat.h: the mesh's range in the blob's triangle copy, when it fits 16 + 16 bits)
+                    const spt_mesh& mm = s.meshes[i];
+                    const uint32_t range = (mm.tri_first < 65536u && mm.tri_count < 65536u) ? (mm.tri_first | (mm.tri_count << 16)) : 0u;
+                    float range_f;
+                    std::memcpy(&range_f, &range, 4);
+                    mesh_rec[2 * i + 1] = make_float4(rn.bmax[0], rn.bmax[1], rn.bmax[2], range_f);
                 }
                 // streaming walker (stream.h): a 4-wide TLAS behind the BLAS nodes (refs of both levels index one array) and
                 // 96-byte instance entry records in its leaf order.  Its boxes only cull (quantised outward, relaxed
@@ -1065,6 +1070,20 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             //  the caller's trees, which serves scenes beyond LDS in that mode, can differ from it in such a pixel)
             if (SPT_WITH_BEZIER && own_bvh && std::getenv("SPT_BEZ_LDS") == nullptr) sc->lds_geo = false;
             if (!sc->lds_geo) assemble(true);
+            // a handful of primitives: every lane tests all of them (flat.h) instead of walking the trees.  The budget is in
+            // triangle tests per ray (an instanced mesh counts once per instance, a sphere as one); SPT_FLAT_BUDGET=0 turns it off.
+            {
+                uint64_t cost = 0;
+                bool ok = sc->lds_geo && own_bvh && s.n_bezier_patches == 0 && s.n_tris < 65536u;   // (the caller's exact trees are walked as they are)
+                for (uint32_t i = 0; i < s.n_instances && ok; ++i) {
+                    const spt_instance& in = s.instances[i];
+                    if (in.prim_type == SPT_PRIM_MESH) cost += s.meshes[in.prim_id].tri_count;
+                    else if (in.prim_type == SPT_PRIM_SPHERE) cost += 1;
+                    else ok = false;
+                }
+                const char* fb = std::getenv("SPT_FLAT_BUDGET");
+                d.flat = ok && s.n_instances != 0 && cost <= (fb ? (uint64_t)std::atoi(fb) : (uint64_t)kFlatBudget) ? 1u : 0u;
+            }
             // fused bounces (k_shade<0, ., kFused>): LDS-resident geometry + the lean simple-scene shade kernel, and
             // the shading tables must fit behind the geometry too (see tab_ld in shading.h)
             {
@@ -1765,6 +1784,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     begin(SPT_K_SHADOW);
                     if (stream_s && count) hipLaunchKernelGGL(k_shadow_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (stream_s) hipLaunchKernelGGL(k_shadow_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
+                    else if (L && sc->d.flat) hipLaunchKernelGGL((k_shadow<true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (L) hipLaunchKernelGGL((k_shadow<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (dyn_shadow && count) hipLaunchKernelGGL(k_shadow_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
                     else if (dyn_shadow) hipLaunchKernelGGL(k_shadow_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, ss, sc->d, ru, b);
@@ -1776,6 +1796,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                         begin(SPT_K_EXTEND);
                         if (stream_e && count) hipLaunchKernelGGL(k_extend_stream<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (stream_e) hipLaunchKernelGGL(k_extend_stream<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
+                        else if (L && sc->d.flat) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (L) hipLaunchKernelGGL((k_extend<true, false>), dim3(kPersistentBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (dyn_extend && count) hipLaunchKernelGGL(k_extend_dyn<true>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);
                         else if (dyn_extend) hipLaunchKernelGGL(k_extend_dyn<false>, dim3(kDynBlocks), dim3(kBlock), lds, st, sc->d, ru, b);

@@ -174,6 +174,9 @@ SWITCHES = [
     {"SPT_NO_PACK_FIRST": "1"},                                                 # bounce-0 records as (slot) instead of (instance | sample, pixel)
     {"SPT_NO_ROW_SPANS": "1"},                                                  # no per-row screen-space spans in k_primary
     {"SPT_RESOLVE_BATCH": "32"},
+    {"SPT_FLAT_BUDGET": "0"},                                                   # tree walkers for every scene (flat.h off)
+    {"SPT_FLAT_BUDGET": "100000"},                                              # exhaustive loops for every LDS-resident scene
+    {"SPT_FLAT_BUDGET": "100000", "SPT_NO_FUSED": "1"},
 ]
 ALL_SWITCHES = sorted({k for s in SWITCHES for k in s})
 

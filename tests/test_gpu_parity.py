@@ -63,6 +63,49 @@ def test_trace_closest_and_any_bit_exact(spt, scene_name):
         assert np.array_equal(occ_ref, occ)
 
 
+@pytest.mark.parametrize("budget", [None, "0", "100000"])
+@pytest.mark.parametrize("scene_name", ["cfg2_cube.json", "t_materials.json", "t_plastic.json"])
+def test_exhaustive_walk_of_small_scenes(spt, scene_name, budget, monkeypatch):
+    """flat.h (scenes of a handful of primitives: every lane tests every primitive; a mesh that few lanes of a wave reach is
+    tested transposed, 64 / T rays x T triangles per pass) against the oracle and, through SPT_FLAT_BUDGET, against the
+    tree walk: waves in which most rays miss the meshes (transposed), waves aimed at them (plain loops), a ragged last
+    wave, rays with a negative t_min inside some waves (the plain loops: the transposed path's keys need t > 0), rays
+    that start inside the objects, finite t_max."""
+    monkeypatch.delenv("SPT_REFERENCE_BVH", raising=False)
+    if budget is None:
+        monkeypatch.delenv("SPT_FLAT_BUDGET", raising=False)
+    else:
+        monkeypatch.setenv("SPT_FLAT_BUDGET", budget)
+    sc = _scene(spt, scene_name)
+    flags = _util.device_oracle_flags()
+    n = 64 * 700 + 37
+    rays = _util.random_rays(sc, n, seed=29)
+    rng = np.random.default_rng(31)
+    inst = sc.array("instances")
+    lo, hi = inst["bmin"].min(axis=0), inst["bmax"].max(axis=0)
+    # first third: directions anywhere (most miss); second third: as random_rays aims them; last third: from inside the boxes
+    k = n // 3
+    d = rng.normal(size=(k, 3))
+    rays["d"][:k] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["o"][2 * k:] = (lo + rng.uniform(0.05, 0.95, size=(n - 2 * k, 3)) * (hi - lo)).astype(np.float32)
+    rays["t_min"][5::97] = np.float32(-2.0)        # a few per wave, some waves none
+    rays["t_min"][64 * 300:64 * 301] = np.float32(0.0)
+    ref = _util.oracle_trace_closest(sc, rays, flags)
+    got = sc.device_scene(0).trace_closest(rays)
+    assert 0.05 < (ref["instance"] >= 0).mean() < 0.95
+    for f in ("t", "v", "w"):
+        assert np.array_equal(ref[f].view(np.uint32), got[f].view(np.uint32)), f
+    for f in ("instance", "prim"):
+        assert np.array_equal(ref[f], got[f]), f
+    rays2 = rays.copy()
+    rays2["t_max"] = np.where(ref["instance"] >= 0, ref["t"] * np.float32(1.5), np.float32(5.0)).astype(np.float32)
+    rays2["t_max"][::2] = (rays2["t_max"][::2] * np.float32(0.5)).astype(np.float32)
+    occ_ref = _util.oracle_trace_any(sc, rays2, flags)
+    assert 0 < occ_ref.sum() < n
+    assert np.array_equal(occ_ref, sc.device_scene(0).trace_any(rays2))
+    sc.close()
+
+
 def test_trace_empty_batch(spt):
     sc = _scene(spt, "cfg2_cube.json")
     rays = np.zeros(0, dtype=spt.RAY_DTYPE)
