@@ -226,22 +226,32 @@ SPT_DEV void flush_visits(const RenderCtx& rc, const LaneVisits& vc, uint32_t cl
     }
 }
 
-// Append a kept vertex (the closest hit of an extension ray, or an in-medium miss: inst < 0) to the hit queue of bounce `bounce_next`:
-// one wave-aggregated append per class present in the wave (usually 1 - 3).  Returns the lane's queue index (valid where keep).
+// Append a kept vertex (the closest hit of an extension ray, or an in-medium miss: inst < 0) to the hit queue of bounce `bounce_next`,
+// filed under its class.  ONE atomic round trip per wave whatever the number of classes present: the first lane of every class adds
+// that class' count to its counter (one atomic instruction, up to kClasses addresses), the bases come back through a shuffle.  (First version: one
+// wave-aggregated append per class present, one after the other - 2 - 3 dependent round trips of 1 - 2 us in a kernel that waits
+// for memory two thirds of its time.)  Returns the lane's queue index (valid where keep).
+// kLds: the class rides in pad[0] of the staged instance record (no global load between the walk and the append).
+template <bool kLds>
 SPT_DEV uint32_t hit_push(const DScene& sc, const RenderCtx& rc, bool keep, int32_t inst, uint32_t bounce_next, uint32_t shard) {
     if (rc.n_classes <= 1u) return shard * rc.shard_cap + wave_push(keep, q_count(rc.counts, bounce_next, Q_HIT, shard));
-    const uint32_t cls = keep ? (inst >= 0 ? (uint32_t)sc.inst_class[inst] : kClasses - 1u) : 0xffffffffu;
-    uint32_t slot = 0u;
-    unsigned long long todo = __ballot(keep);
-    while (todo != 0ull) {       // wave-uniform: every pass retires all lanes of one class
-        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-        const uint32_t c = (uint32_t)__shfl((int)cls, (int)leader, 64);
-        const bool mine = keep && cls == c;
-        const uint32_t pos = wave_push(mine, q_count(rc.counts, bounce_next, q_hit_kind(c), shard));
-        if (mine) slot = c * rc.class_cap + shard * rc.shard_cap + pos;
-        todo &= ~__ballot(mine);
+    uint32_t cls = 0xffffffffu;
+    if (keep) cls = inst < 0 ? kClasses - 1u : (kLds ? __float_as_uint(geo_ld<true>(sc, sc.o_inst + 12u * (uint32_t)inst + 10u).w) : (uint32_t)sc.inst_class[inst]);
+    // the lanes of one class elect their first lane; the leaders of all classes issue their atomics in the same instruction
+    // (only lanes that carry a kept vertex take part: the caller may run with some lanes switched off)
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (uint32_t c = 0; c < kClasses; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) mine = m;
     }
-    return slot;
+    const uint32_t lane = lane_id();
+    const uint32_t leader = keep ? (uint32_t)__ffsll((long long)mine) - 1u : lane;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+    uint32_t base = 0u;
+    if (keep && lane == leader) base = atomicAdd(q_count(rc.counts, bounce_next, q_hit_kind(cls), shard), (uint32_t)__popcll(mine));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    return cls * rc.class_cap + shard * rc.shard_cap + base + rank;
 }
 
 SPT_DEV uint32_t pack_meta(uint32_t depth, int32_t medium) { return depth | ((uint32_t)(medium + 1) << 8); }
@@ -375,7 +385,7 @@ __global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI :
         //  but MEASURED the same 2.70 ms - the atomic is not what the kernel waits for)
         // (general pipeline: camera hits are filed by BxDF class too, see kClasses - object boundaries inside a wave cost the bounce-0
         //  shade kernel a third of its lanes; the compact record below sits at the hit's own index, so qa.d_pdf spans all classes)
-        const uint32_t slot = rc.n_classes > 1u ? hit_push(sc, rc, hit, h.inst, 0u, shard) : shard * rc.shard_cap + wave_push(hit, hit_counter);
+        const uint32_t slot = rc.n_classes > 1u ? hit_push<kLds>(sc, rc, hit, h.inst, 0u, shard) : shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {
             // bounce-0 records are compact: origin (eye), t_min, throughput (1), last_pdf (0), depth, medium and
             // the RNG stream (a function of pixel and sample = of the slot) are constants that k_shade<.., true>
@@ -873,14 +883,11 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_SHD_L 
         for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
             const bool active = i0 + lane_id() < n;
             const uint32_t idx = qbase + (active ? i0 + lane_id() : 0u);
-            const float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx];
+            const float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx], c = rc.shadow.contrib_slot[idx];
             DRay r;
             r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
             const bool occluded = flat_any(sc, r, b.w, active);
-            if (active && !occluded) {
-                const float4 c = rc.shadow.contrib_slot[idx];
-                rad_add(rc, __float_as_uint(c.w), mk3(c));
-            }
+            if (active && !occluded) rad_add(rc, __float_as_uint(c.w), mk3(c));
         }
         return;
     }
@@ -904,39 +911,37 @@ __global__ void __launch_bounds__(256, (kLds && !SPT_WITH_BEZIER) ? SPT_W_EXT_L 
     LaneVisits vc{0u, 0u, 0u};
     const uint32_t qbase = shard * rc.shard_cap;
     const uint32_t stride = (gridDim.x / kShards) * blockDim.x;
+    const bool env = sc.env_w != 0u;
     for (uint32_t i0 = (blockIdx.x / kShards) * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
         const bool active = i0 + lane_id() < n;
-        const uint32_t idx = qbase + i0 + lane_id();
-        bool keep = false, in_medium = false;
+        const uint32_t idx = qbase + (active ? i0 + lane_id() : 0u);   // (inactive lanes read entry 0 of the shard and discard what they find)
+        // everything the vertex may need is requested with the ray: waiting for the throughput of a miss after the walk
+        // would be a memory round trip of its own, in a kernel that spends two thirds of its time waiting for those
+        const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
+        const uint32_t meta = __float_as_uint(rc.qb.lsi_meta[idx].w);
+        float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (env) c = rc.qb.thr_slot[idx];
+        DRay r;
+        r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
         DHit h;
         h.inst = -1; h.t = SPT_F32_MAX; h.prim = -1; h.v = 0.0f; h.w = 0.0f;
-        if (kFlat) {   // flat.h wants whole waves (inactive lanes read entry 0 of the shard and discard what they find)
-            const float4 a = rc.qb.o_tmin[active ? idx : qbase];
-            const float4 b = rc.qb.d_pdf[active ? idx : qbase];
-            DRay r;
-            r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-            h = flat_closest(sc, r, SPT_F32_MAX, active);
-        }
+        if (kFlat) h = flat_closest(sc, r, SPT_F32_MAX, active);     // (whole waves, see flat.h)
+        else if (active) h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
+        bool keep = false;
         if (active) {
-            const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
-            const uint32_t meta = __float_as_uint(rc.qb.lsi_meta[idx].w);
-            DRay r;
-            r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-            if (!kFlat) h = trace_closest<kLds, kCount>(sc, r, SPT_F32_MAX, &vc);
-            in_medium = (meta >> 8) != 0u;
+            const bool in_medium = (meta >> 8) != 0u;
             if (h.inst >= 0 || in_medium) {
                 keep = true;
-            } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
-                const float4 c = rc.qb.thr_slot[idx];
-                f3 env;
+            } else if (env) {  // pt.rs:97-111, curr_depth > 0 here
+                f3 env_rgb;
                 float env_pdf;
-                env_strength_pdf(sc, r.d, &env, &env_pdf);
+                env_strength_pdf(sc, r.d, &env_rgb, &env_pdf);
                 float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
-                rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
+                rad_add(rc, __float_as_uint(c.w), (mk3(c) * env_rgb) * weight);
             }
         }
         // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        const uint32_t slot = hit_push(sc, rc, keep, h.inst, bounce + 1u, shard);
+        const uint32_t slot = hit_push<kLds>(sc, rc, keep, h.inst, bounce + 1u, shard);
         if (keep) {
             rc.hits.t_v_w_prim[slot] = make_float4(h.t, h.v, h.w, __int_as_float(h.prim));
             rc.hits.inst_src[slot] = make_uint2((uint32_t)h.inst, idx);
@@ -1062,7 +1067,7 @@ __global__ void __launch_bounds__(256, 2) k_extend_dyn(DScene sc, RenderCtx rc, 
             busy = false;
         }
         // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        const uint32_t slot = hit_push(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
+        const uint32_t slot = hit_push<false>(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
         if (keep) {
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
             rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
@@ -1166,7 +1171,7 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
             busy = false;
         }
         // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        const uint32_t slot = hit_push(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
+        const uint32_t slot = hit_push<false>(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
         if (keep) {
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
             rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
@@ -1274,7 +1279,7 @@ __global__ void __launch_bounds__(256, 2) k_primary_stream(DScene sc, RenderCtx 
                 slot_mask = 0u;
             }
         }
-        const uint32_t slot = rc.n_classes > 1u ? hit_push(sc, rc, hit, wk.h.inst, 0u, shard) : shard * rc.shard_cap + wave_push(hit, hit_counter);
+        const uint32_t slot = rc.n_classes > 1u ? hit_push<false>(sc, rc, hit, wk.h.inst, 0u, shard) : shard * rc.shard_cap + wave_push(hit, hit_counter);
         if (hit) {
             rc.qa.d_pdf[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)ri));
             rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));

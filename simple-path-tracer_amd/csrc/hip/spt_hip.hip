@@ -926,6 +926,32 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
         for (int i = 0; i < 3; ++i) d.env_scale[i] = s.env.scale[i];
         d.stack_cap = cap;
         d.fast_slab = own_bvh ? 1u : 0u;
+        // the class a hit on each instance is queued under for the shade stage of bounce >= 1 (kernels.h, kClasses): by the code
+        // path its material takes through mat_sample / mat_eval / mat_pdf and by whether it has a light sample at all
+        std::vector<uint8_t> cls(std::max<uint32_t>(s.n_instances, 1u), 0);
+        for (uint32_t i = 0; i < s.n_instances; ++i) {
+            const spt_material& m = s.materials[s.surfaces[s.instances[i].surface].material];
+            uint32_t b = m.bxdf;
+            if (m.recipe != 0u) {      // evaluated per hit: the kind the recipe usually resolves to
+                switch (s.material_recipes[m.recipe - 1u].type) {
+                case SPT_MAT_LAMBERT: b = SPT_BXDF_LAMBERT; break;
+                case SPT_MAT_CONDUCTOR: b = SPT_BXDF_MICROFACET_CONDUCTOR; break;
+                case SPT_MAT_DIELECTRIC: b = SPT_BXDF_MICROFACET_DIELECTRIC; break;
+                default: b = SPT_BXDF_MICROFACET_PLASTIC; break;
+                }
+            }
+            switch (b) {
+            case SPT_BXDF_LAMBERT: cls[i] = 0; break;
+            case SPT_BXDF_MICROFACET_CONDUCTOR: cls[i] = 1; break;
+            case SPT_BXDF_SPECULAR_CONDUCTOR: cls[i] = 2; break;
+            case SPT_BXDF_MICROFACET_DIELECTRIC: cls[i] = 3; break;
+            case SPT_BXDF_SPECULAR_DIELECTRIC: cls[i] = 4; break;
+            case SPT_BXDF_PSEUDO: cls[i] = 5; break;
+            default: cls[i] = 6; break;       // the plastic / PBR lobes, glints
+            }
+        }
+        sc->inst_class.upload(cls.data(), cls.size());
+        d.inst_class = sc->inst_class.as<uint8_t>();
         {
             // one float4 blob for everything the traversal touches: [tlas | instances | meshes | spheres | blas | tri]
             std::vector<float4> blob;
@@ -1052,7 +1078,11 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 }
                 d.o_sinst = append(sinst.data(), sinst.size() * 16);
                 d.o_tlas = append(wtlas.data(), wtlas.size() * 16);
-                d.o_inst = append(s.instances, (size_t)s.n_instances * sizeof(spt_instance));
+                {   // the instance records as they are, pad[0] carrying the instance's class (hit_push<true> reads it from the staged copy)
+                    std::vector<spt_instance> inst_copy(s.instances, s.instances + s.n_instances);
+                    for (uint32_t i = 0; i < s.n_instances; ++i) { const uint32_t c = cls[i]; std::memcpy(&inst_copy[i].pad[0], &c, 4); }
+                    d.o_inst = append(inst_copy.data(), (size_t)s.n_instances * sizeof(spt_instance));
+                }
                 d.o_mesh = append(mesh_rec.data(), mesh_rec.size() * 16);
                 d.o_sph = append(s.spheres, (size_t)s.n_spheres * sizeof(spt_sphere));
                 d.o_blas = append(wblas.data(), wblas.size() * 16);
@@ -1223,33 +1253,6 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             d.recipes = sc->recipes.as<uint4>();
         }
         sc->simple = simple;
-        {   // the class a hit on each instance is queued under for the shade stage of bounce >= 1 (kernels.h, kClasses): by the code
-            // path its material takes through mat_sample / mat_eval / mat_pdf and by whether it has a light sample at all
-            std::vector<uint8_t> cls(std::max<uint32_t>(s.n_instances, 1u), 0);
-            for (uint32_t i = 0; i < s.n_instances; ++i) {
-                const spt_material& m = s.materials[s.surfaces[s.instances[i].surface].material];
-                uint32_t b = m.bxdf;
-                if (m.recipe != 0u) {      // evaluated per hit: the kind the recipe usually resolves to
-                    switch (s.material_recipes[m.recipe - 1u].type) {
-                    case SPT_MAT_LAMBERT: b = SPT_BXDF_LAMBERT; break;
-                    case SPT_MAT_CONDUCTOR: b = SPT_BXDF_MICROFACET_CONDUCTOR; break;
-                    case SPT_MAT_DIELECTRIC: b = SPT_BXDF_MICROFACET_DIELECTRIC; break;
-                    default: b = SPT_BXDF_MICROFACET_PLASTIC; break;
-                    }
-                }
-                switch (b) {
-                case SPT_BXDF_LAMBERT: cls[i] = 0; break;
-                case SPT_BXDF_MICROFACET_CONDUCTOR: cls[i] = 1; break;
-                case SPT_BXDF_SPECULAR_CONDUCTOR: cls[i] = 2; break;
-                case SPT_BXDF_MICROFACET_DIELECTRIC: cls[i] = 3; break;
-                case SPT_BXDF_SPECULAR_DIELECTRIC: cls[i] = 4; break;
-                case SPT_BXDF_PSEUDO: cls[i] = 5; break;
-                default: cls[i] = 6; break;       // the plastic / PBR lobes, glints
-                }
-            }
-            sc->inst_class.upload(cls.data(), cls.size());
-            d.inst_class = sc->inst_class.as<uint8_t>();
-        }
         if (s.n_instances) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             bool finite = true;
