@@ -1097,29 +1097,34 @@ __global__ void __launch_bounds__(256, 2) k_shadow_stream(DScene sc, RenderCtx r
     uint32_t idx = 0;
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
     for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
-        const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
-        if (!drained && n_busy < rc.stream_refill_below) {
-            const uint32_t i = wave_pull(!busy, cursor);
-            if (!busy && i < n) {
-                idx = qbase + i;
-                const float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx];
-                DRay r;
-                r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-                wk.begin(sc, r, b.w);
-                busy = true;
+        // Finished lanes are retired when the wave refills, not in the round they finish in: a retirement waits for two
+        // dependent loads (the contribution, then the radiance slot), and paying that once per refill instead of once per
+        // round keeps the walking lanes walking.
+        const uint32_t n_walking = (uint32_t)__popcll(__ballot(busy && !wk.done));
+        if (n_walking < rc.stream_refill_below) {
+            if (busy && wk.done) {
+                if (wk.h.inst < 0) {  // not occluded
+                    const float4 c = rc.shadow.contrib_slot[idx];
+                    rad_add(rc, __float_as_uint(c.w), mk3(c));
+                }
+                busy = false;
             }
-            // the cursor only grows: once any lane was refused the shard is empty for good
-            drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
+            if (!drained) {
+                const uint32_t i = wave_pull(!busy, cursor);
+                if (!busy && i < n) {
+                    idx = qbase + i;
+                    const float4 a = rc.shadow.o_tmin[idx], b = rc.shadow.d_tmax[idx];
+                    DRay r;
+                    r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+                    wk.begin(sc, r, b.w);
+                    busy = true;
+                }
+                // the cursor only grows: once any lane was refused the shard is empty for good
+                drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
+            }
         }
         if (__ballot(busy) == 0ull) break;
         wk.run(sc, rc.stream_rounds, spill_mem);
-        if (busy && wk.done) {
-            if (wk.h.inst < 0) {  // not occluded
-                const float4 c = rc.shadow.contrib_slot[idx];
-                rad_add(rc, __float_as_uint(c.w), mk3(c));
-            }
-            busy = false;
-        }
     }
     if (kCount) flush_visits(rc, wk.vc, 1u);
 }
@@ -1139,43 +1144,47 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 2 : SPT_W_EXT) k_extend
     uint32_t idx = 0;
     // every wave leaves this loop: the queue is finite and every walk ends; the bound is a guard against a corrupt scene
     for (uint32_t guard = 0; guard < kStreamGuard; ++guard) {
-        const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
-        if (!drained && n_busy < rc.stream_refill_below) {
-            const uint32_t i = wave_pull(!busy, cursor);
-            if (!busy && i < n) {
-                idx = qbase + i;
-                const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
-                in_medium = (__float_as_uint(rc.qb.lsi_meta[idx].w) >> 8) != 0u;
-                DRay r;
-                r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
-                wk.begin(sc, r, SPT_F32_MAX);
-                busy = true;
+        // Finished lanes are retired when the wave refills, not in the round they finish in (see k_shadow_stream): a
+        // retirement is a class lookup, an atomic append and, for a miss under an environment, a read-modify-write.
+        const uint32_t n_walking = (uint32_t)__popcll(__ballot(busy && !wk.done));
+        if (n_walking < rc.stream_refill_below) {
+            const bool retire = busy && wk.done;
+            bool keep = false;
+            if (retire) {
+                if (wk.h.inst >= 0 || in_medium) {
+                    keep = true;
+                } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
+                    const float4 b = rc.qb.d_pdf[idx], c = rc.qb.thr_slot[idx];
+                    f3 env;
+                    float env_pdf;
+                    env_strength_pdf(sc, mk3(b), &env, &env_pdf);
+                    const float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
+                    rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
+                }
+                busy = false;
             }
-            drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
+            // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
+            const uint32_t slot = hit_push<false>(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
+            if (keep) {
+                rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
+                rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
+            }
+            if (!drained) {
+                const uint32_t i = wave_pull(!busy, cursor);
+                if (!busy && i < n) {
+                    idx = qbase + i;
+                    const float4 a = rc.qb.o_tmin[idx], b = rc.qb.d_pdf[idx];
+                    in_medium = (__float_as_uint(rc.qb.lsi_meta[idx].w) >> 8) != 0u;
+                    DRay r;
+                    r.o = mk3(a); r.t_min = a.w; r.d = mk3(b);
+                    wk.begin(sc, r, SPT_F32_MAX);
+                    busy = true;
+                }
+                drained = __ballot(!busy && i >= n && i != 0xffffffffu) != 0ull;
+            }
         }
         if (__ballot(busy) == 0ull) break;
         wk.run(sc, rc.stream_rounds, spill_mem);
-        bool retire = busy && wk.done;
-        bool keep = false;
-        if (retire) {
-            if (wk.h.inst >= 0 || in_medium) {
-                keep = true;
-            } else if (sc.env_w != 0u) {  // pt.rs:97-111, curr_depth > 0 here
-                const float4 b = rc.qb.d_pdf[idx], c = rc.qb.thr_slot[idx];
-                f3 env;
-                float env_pdf;
-                env_strength_pdf(sc, mk3(b), &env, &env_pdf);
-                const float weight = power_heuristic(b.w, pdf_env_light(sc) * env_pdf);
-                rad_add(rc, __float_as_uint(c.w), (mk3(c) * env) * weight);
-            }
-            busy = false;
-        }
-        // a kept path leaves only its hit and the index of its record (which stays where the shade stage wrote it)
-        const uint32_t slot = hit_push<false>(sc, rc, keep, wk.h.inst, bounce + 1u, shard);
-        if (keep) {
-            rc.hits.t_v_w_prim[slot] = make_float4(wk.h.t, wk.h.v, wk.h.w, __int_as_float(wk.h.prim));
-            rc.hits.inst_src[slot] = make_uint2((uint32_t)wk.h.inst, idx);
-        }
     }
     if (kCount) flush_visits(rc, wk.vc, 2u);
 }

@@ -1648,7 +1648,7 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
             // a finished lane that waits several rounds for its wave costs more than the refill check
             // if-if with 4 rounds per check: 87.4 ms; 8 rounds 95.2; while-while (SPT_STREAM_IFIF=0) 100 - 121 ms
             rc.stream_rounds = std::max(1u, std::min(255u, env_u32("SPT_STREAM_ROUNDS", 4u))) | (env_u32("SPT_STREAM_IFIF", 1u) ? 0x100u : 0u);
-            rc.stream_refill_below = env_u32("SPT_STREAM_REFILL", 40u);
+            rc.stream_refill_below = std::max(1u, std::min(64u, env_u32("SPT_STREAM_REFILL", 40u)));
             rc.visits = sc->visits.as<unsigned long long>();
             rc.debug_normal = (p.flags & SPT_RENDER_DEBUG_NORMAL) ? 1u : 0u;
             rc.row_span = row_span_dev;
