@@ -104,6 +104,17 @@ def valu_block(kernel_class, kernel_symbol_regex, avg_launch_ms, launches_per_st
     return out
 
 
+def counting_variant(kernel_name):
+    """True for the SPT_RENDER_COUNT_VISITS instantiations (kCount = true), which the timed runs never launch."""
+    import re
+    m = re.match(r"(k_\w+)<([^>]*)>", kernel_name)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(",")]
+    pos = {"k_primary": 2, "k_extend": 1, "k_shadow": 1, "k_primary_stream": 1}.get(m.group(1), 0 if m.group(1).endswith(("_stream", "_dyn")) else None)
+    return pos is not None and pos < len(args) and args[pos] == "true"
+
+
 def oracle_util():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _util
@@ -542,7 +553,7 @@ def other_configs(spt, device, only=""):
         if pj:
             byt, disp = 0.0, 0
             for kname, t in pj.items():
-                if kname.startswith(cls_kernels) and "true>" not in kname.split("(")[0][-8:] and "FETCH_SIZE" in t and t.get("dispatches"):
+                if kname.startswith(cls_kernels) and not counting_variant(kname) and "FETCH_SIZE" in t and t.get("dispatches"):
                     byt += (2.0 * t["FETCH_SIZE"] + t.get("WRITE_SIZE", 0.0)) * 1024.0
                     disp += t["dispatches"]
             launches = int(pst.kernel_launches[list(spt.KERNEL_NAMES).index(dom)]) if dom in list(spt.KERNEL_NAMES) else 0
@@ -551,9 +562,15 @@ def other_configs(spt, device, only=""):
         fetch_gbs = alg[dom] / (kms[dom] * 1e-3) / 1e9
         if hbm is not None:
             gbs = hbm / (kms[dom] * 1e-3) / 1e9
-            limited = {"shade": "VALU issue at ~0.36 lane utilisation: the vertices of bounce >= 1 arrive in an order that splits every wave over the kernel's branches (DESIGN.md section 6)",
-                       "shade_first": "VALU issue (0.69 lane utilisation)"}.get(dom, "divergent traversal: instruction issue for half-empty waves (node step / triangle leaf / instance entry in turn) "
-                                                                                     "and dependent fetches served by L2 / Infinity Cache (DESIGN.md section 6)")
+            lanes = [t["derived"]["valu_lane_utilisation"] for kname, t in pj.items()
+                     if kname.startswith(cls_kernels) and not counting_variant(kname) and "derived" in t and "valu_lane_utilisation" in t["derived"]]
+            lane_txt = ("%.2f" % (sum(lanes) / len(lanes))) if lanes else "n/a"
+            limited = {"shade": "memory system: the stage streams every vertex's hit, path and shadow records (~220 B) and samples the environment map; its "
+                                "L2-miss traffic is the fraction below (Infinity-Cache hits included), VALU lane utilisation %s with class-binned queues "
+                                "(DESIGN.md section 6)" % lane_txt,
+                       "shade_first": "memory system + VALU issue (lane utilisation %s)" % lane_txt}.get(
+                dom, "dependent fetches: ~9 node / leaf / instance records per ray one after the other at 4 waves per SIMD, served by L1 (hit rate 0.92) / L2 / "
+                     "Infinity Cache; VALU lane utilisation %s (DESIGN.md section 6)" % lane_txt)
             entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "limited_by": limited,
                                  "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "hbm_MB": round(hbm / 1e6, 1), "ms": round(kms[dom], 2),

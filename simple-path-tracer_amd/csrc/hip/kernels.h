@@ -456,8 +456,11 @@ SPT_DEV void rad_store(const RenderCtx& rc, uint32_t slot, f3 c) {
 #define SPT_SHADE_HEAVY_WAVES 2   // waves / SIMD the probe-only (kFeat 3) and glint-only (kFeat 4) kernels are compiled for: unbounded they need
                                   // 248 - 266 resp. 284 - 300 VGPRs, i.e. mostly ONE wave; bounded to 256 a few registers spill (measured: DESIGN.md)
 #endif
+#ifndef SPT_SHADE1_WAVES
+#define SPT_SHADE1_WAVES 0   // waves / SIMD the general un-fused kernel (kFeat 1) is compiled for; 0 = no bound (186 - 206 VGPRs, 2 waves)
+#endif
 template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab, bool kLoop = false>
-__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : ((kFeat == 3 || kFeat == 4) ? SPT_SHADE_HEAVY_WAVES : 1)) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : ((kFeat == 3 || kFeat == 4) ? SPT_SHADE_HEAVY_WAVES : ((kFeat == 1 && SPT_SHADE1_WAVES) ? SPT_SHADE1_WAVES : 1))) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     static_assert(!kLoop || (kFused && !kFirst), "the in-kernel bounce loop exists for the fused kernels of bounce >= 1");
     // kFeat 3: Subsurface substrates (the probe), 4: position-normal distributions (the glint walks), 5: both
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3 || kFeat == 5, kPndf = kFeat == 4 || kFeat == 5;
