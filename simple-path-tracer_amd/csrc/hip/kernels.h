@@ -31,7 +31,7 @@
 #pragma once
 // waves / SIMD the latency-bound large-scene kernels are compiled for (see DESIGN.md "Registers and occupancy")
 #ifndef SPT_W_EXT
-#define SPT_W_EXT 4   // cfg5 extension rays (streaming walker): 88.9 ms at 3 waves (146 VGPRs), 78.0 at 4 (128, 14 spilled) and 69.6 once a leaf loads its triangles two at a time (3 spilled); 5 waves (96, 67 - 95 spilled): 104 - 129 ms
+#define SPT_W_EXT 5   // cfg5 extension rays (streaming walker): round 2 - 88.9 ms at 3 waves (146 VGPRs), 78.0 at 4 (128, 14 spilled), 69.6 once a leaf loads its triangles two at a time; 5 waves then meant 67 - 95 spilled VGPRs and 104 - 129 ms.  Round 3, without the SLP vectoriser's packed pairs the kernel needs 105 VGPRs unbounded: 5 waves (96, NONE spilled) 69.3 -> 62.4 ms
 #endif
 #ifndef SPT_W_SHD_L
 #define SPT_W_SHD_L 6   // cfg4 shadow (LDS-resident): 17.2 ms unbounded (84 VGPRs, 5 waves), 17.1 at 6 (80), 21.3 at 8 (64, 30 spilled)
@@ -42,8 +42,11 @@
 #ifndef SPT_W_SHD
 #define SPT_W_SHD 6   // cfg5 shadow: 9.9 ms at 4 waves (98 VGPRs), 9.1 at 5, 8.75 at 6 (80 VGPRs, 5 spilled)
 #endif
+#ifndef SPT_W_PRI_L
+#define SPT_W_PRI_L 5   // k_primary of LDS-resident scenes (cfg2, cfg4): unbounded 106 VGPRs = 4 waves; MEASURED at 5 (96, 5 spilled): 0.736 -> 0.655 ms per launch on cfg2 (89.6 -> 94.4 Gsamples/s), cfg4 8.7 -> 8.2 ms
+#endif
 #ifndef SPT_W_PRI
-#define SPT_W_PRI 5   // cfg5 primary: 8.6 ms at 4 waves (111 VGPRs), 8.3 at 5 (96, 9 spilled), 9.6 at 6 (80, 28 spilled)
+#define SPT_W_PRI 6   // cfg5 primary: round 2 - 8.6 ms at 4 waves (111 VGPRs), 8.3 at 5 (96, 9 spilled), 9.6 at 6 (80, 28 spilled); round 3 (no packed pairs: 93 VGPRs unbounded) 8.0 at 5, 7.8 at 6 (80, 8 spilled)
 #endif
 #ifndef SPT_PRIMARY_PIN
 #define SPT_PRIMARY_PIN 1   // k_primary keeps its camera terms in VGPRs instead of (spilled) SGPRs, see the kernel
@@ -281,7 +284,7 @@ SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % 
 // which adds the slots in sample order: the same additions in the same order as the register sum of the
 // un-chunked kernel (a miss adds exactly +0 or its environment term), so the film is bit-identical.
 template <bool kLds, bool kChunked = false, bool kCount = false>
-__global__ void __launch_bounds__(256, (!kLds && !SPT_WITH_BEZIER) ? SPT_W_PRI : 1) k_primary(DScene sc, RenderCtx rc) {
+__global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 1 : (kLds ? SPT_W_PRI_L : SPT_W_PRI)) k_primary(DScene sc, RenderCtx rc) {
     stage_geometry<kLds>(sc);
     LaneVisits vc{0u, 0u, 0u};
     const uint32_t tile = kChunked ? blockIdx.x % rc.n_tiles : blockIdx.x, chunk = kChunked ? blockIdx.x / rc.n_tiles : 0u;
@@ -457,10 +460,12 @@ SPT_DEV void rad_store(const RenderCtx& rc, uint32_t slot, f3 c) {
                                   // 248 - 266 resp. 284 - 300 VGPRs, i.e. mostly ONE wave; bounded to 256 a few registers spill (measured: DESIGN.md)
 #endif
 #ifndef SPT_SHADE1_WAVES
-#define SPT_SHADE1_WAVES 0   // waves / SIMD the general un-fused kernel (kFeat 1) is compiled for; 0 = no bound (186 - 206 VGPRs, 2 waves)
+#define SPT_SHADE1_WAVES 3   // waves / SIMD the BOUNCE-0 instance of the general un-fused kernel (kFeat 1) is compiled for (0 = no bound: 186 VGPRs, 2 waves).
+                             // MEASURED at 3 (168 VGPRs, 5 - 9 spilled): cfg4 shade_first 20.9 -> 19.5 ms, cfg5 10.9 -> 9.5.  The later-bounce instance
+                             // (206 VGPRs) would spill 110 - 140 at 3 waves: cfg4 22.1 -> 24.5 ms, so it stays unbounded
 #endif
 template <int kFeat, bool kFirst, bool kFused = false, bool kTab = kFused, bool kGeoLds = kTab, bool kLoop = false>
-__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : ((kFeat == 3 || kFeat == 4) ? SPT_SHADE_HEAVY_WAVES : ((kFeat == 1 && SPT_SHADE1_WAVES) ? SPT_SHADE1_WAVES : 1))) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
+__global__ void __launch_bounds__(256, (kFeat == 0 && kFirst && kFused && SPT_SHADE0_WAVES) ? SPT_SHADE0_WAVES : ((kFeat == 3 || kFeat == 4) ? SPT_SHADE_HEAVY_WAVES : ((kFeat == 1 && kFirst && SPT_SHADE1_WAVES) ? SPT_SHADE1_WAVES : 1))) k_shade(DScene sc, RenderCtx rc, uint32_t bounce) {
     static_assert(!kLoop || (kFused && !kFirst), "the in-kernel bounce loop exists for the fused kernels of bounce >= 1");
     // kFeat 3: Subsurface substrates (the probe), 4: position-normal distributions (the glint walks), 5: both
     constexpr bool kSimple = kFeat == 0, kTex = kFeat >= 2, kSubsurface = kFeat == 3 || kFeat == 5, kPndf = kFeat == 4 || kFeat == 5;
