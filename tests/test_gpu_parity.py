@@ -106,6 +106,81 @@ def test_exhaustive_walk_of_small_scenes(spt, scene_name, budget, monkeypatch):
     sc.close()
 
 
+@pytest.mark.parametrize("aggregate", ["bvh", "group"])
+def test_exhaustive_walk_with_awkward_mesh_sizes(spt, tmp_path, aggregate, monkeypatch):
+    """flat.h on meshes whose triangle counts do not divide 64 (an icosahedron: 20, fans of 7, 5 and 3 triangles), one of them
+    instanced twice under different transforms, spheres between them, BVH and GROUP aggregates: rays and films == oracle.
+    SPT_FLAT_BUDGET lifts the scene (62 triangle tests per ray) into the exhaustive mode."""
+    import json
+    monkeypatch.delenv("SPT_REFERENCE_BVH", raising=False)
+    monkeypatch.setenv("SPT_FLAT_BUDGET", "1000")
+    os.makedirs(tmp_path / "models")
+    g = (1.0 + 5.0 ** 0.5) / 2.0
+    iv = [(-1, g, 0), (1, g, 0), (-1, -g, 0), (1, -g, 0), (0, -1, g), (0, 1, g), (0, -1, -g), (0, 1, -g), (g, 0, -1), (g, 0, 1), (-g, 0, -1), (-g, 0, 1)]
+    it = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+          (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    def obj(name, verts, tris):
+        with open(tmp_path / "models" / name, "w") as f:
+            for v in verts:
+                f.write("v %r %r %r\n" % tuple(float(c) for c in v))
+            f.write("vn 0 1 0\nvt 0 0\n")
+            for t in tris:
+                f.write("f " + " ".join("%d/1/1" % (i + 1) for i in t) + "\n")
+    def fan(n):
+        ring = [(np.cos(2 * np.pi * k / (n + 1)), 0.2 * np.sin(3.0 * k), np.sin(2 * np.pi * k / (n + 1))) for k in range(n + 1)]
+        return [(0.0, 0.3, 0.0)] + ring, [(0, 1 + k, 2 + k) for k in range(n)]
+    obj("ico.obj", iv, it)
+    for n in (7, 5, 3):
+        v, t = fan(n)
+        obj("fan%d.obj" % n, v, t)
+    scene = {"cameras": {"type": "perspective", "name": "c", "eye": [0.0, 2.5, 9.0], "forward": [0.0, -0.2, -1.0], "up": [0.0, 1.0, 0.0], "fov": 45.0},
+             "textures": [{"type": "scalar", "name": "w", "value": [0.8, 0.8, 0.75]}, {"type": "scalar", "name": "gn", "value": [0.14, 0.37, 1.44]},
+                          {"type": "scalar", "name": "gk", "value": [3.98, 2.38, 1.6]}, {"type": "scalar", "name": "r", "value": [0.3, 0.3, 0.3]},
+                          {"type": "scalar", "name": "one", "value": [1.0, 1.0, 1.0]}],
+             "materials": [{"type": "lambert", "name": "m", "albedo": "w"}, {"type": "conductor", "name": "g", "ior": "gn", "ior_k": "gk", "roughness": "r"},
+                           {"type": "dielectric", "name": "d", "int_ior": 1.5, "reflectance": "one", "transmittance": "one", "roughness": "r"}],
+             "mediums": [], "surfaces": [],
+             "primitives": [{"type": "trimesh", "name": "ico", "obj_file": "models/ico.obj"}, {"type": "trimesh", "name": "fan7", "obj_file": "models/fan7.obj"},
+                            {"type": "trimesh", "name": "fan5", "obj_file": "models/fan5.obj"}, {"type": "trimesh", "name": "fan3", "obj_file": "models/fan3.obj"},
+                            {"type": "sphere", "name": "ball", "radius": 1.0}],
+             "instances": [{"name": "floor", "primitive": "fan7", "material": "m", "scale": [9.0, 1.0, 9.0], "translate": [0.0, -1.6, 0.0]},
+                           {"name": "ico1", "primitive": "ico", "material": "g", "scale": [0.7, 0.7, 0.7], "translate": [-2.0, 0.0, 0.0]},
+                           {"name": "ball1", "primitive": "ball", "material": "d", "scale": [0.8, 0.8, 0.8], "translate": [0.3, -0.4, 1.0]},
+                           {"name": "ico2", "primitive": "ico", "material": "d", "scale": [0.5, 0.9, 0.5], "rotate": [20.0, 35.0, 0.0], "translate": [2.2, 0.2, -0.5]},
+                           {"name": "f5", "primitive": "fan5", "material": "m", "scale": [1.5, 1.0, 1.5], "rotate": [60.0, 0.0, 10.0], "translate": [0.0, 1.8, -2.0]},
+                           {"name": "f3", "primitive": "fan3", "material": "g", "scale": [1.2, 1.0, 1.2], "rotate": [-40.0, 20.0, 0.0], "translate": [-0.5, 0.9, 2.0]},
+                           {"name": "ball2", "primitive": "ball", "material": "m", "scale": [0.4, 0.4, 0.4], "translate": [1.4, -1.0, 2.2]}],
+             "lights": [{"type": "directional", "name": "sun", "direction": [-0.4, -1.0, -0.3], "strength": [3.0, 2.9, 2.7]}],
+             "environment": {"type": "color", "color": [0.3, 0.35, 0.45]}}
+    if aggregate == "group":
+        scene["aggregate"] = "group"
+    path = tmp_path / "awkward.json"
+    path.write_text(json.dumps(scene))
+    sc = spt.load_scene(str(path))
+    assert sc.desc.n_instances == 7 and sc.desc.n_tris == 35
+    flags = _util.device_oracle_flags()
+    n = 64 * 900 + 11
+    rays = _util.random_rays(sc, n, seed=41)
+    d = np.random.default_rng(43).normal(size=(n // 2, 3))
+    rays["d"][:n // 2] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)   # half of them anywhere: sparse box hits
+    ref = _util.oracle_trace_closest(sc, rays, flags)
+    got = sc.device_scene(0).trace_closest(rays)
+    assert 0.1 < (ref["instance"] >= 0).mean() < 0.9 and len(set(ref["instance"].tolist())) == 8
+    assert ref.tobytes() == got.tobytes()
+    rays2 = rays.copy()
+    rays2["t_max"] = np.where(ref["instance"] >= 0, ref["t"] * np.float32(1.5), np.float32(5.0)).astype(np.float32)
+    rays2["t_max"][::2] = (rays2["t_max"][::2] * np.float32(0.5)).astype(np.float32)
+    assert np.array_equal(_util.oracle_trace_any(sc, rays2, flags), sc.device_scene(0).trace_any(rays2))
+    r = spt.PathTracer(max_depth=6, sampler=spt.SAMPLER_RANDOM, spp=8, seed=2)
+    w, h = 160, 120
+    ref_film, _ = _util.oracle_render(sc, r, w, h, flags=flags)
+    film = r.render_shard(sc, spt.OutputConfig(w, h))
+    nan = np.isnan(ref_film)
+    assert nan.mean() < 1e-3 and np.array_equal(nan, np.isnan(film))
+    assert np.array_equal(film.view(np.uint32)[~nan], ref_film.view(np.uint32)[~nan])
+    sc.close()
+
+
 def test_trace_empty_batch(spt):
     sc = _scene(spt, "cfg2_cube.json")
     rays = np.zeros(0, dtype=spt.RAY_DTYPE)
