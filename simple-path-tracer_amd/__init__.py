@@ -504,9 +504,10 @@ class PathTracer:
         if reuse_output and rows.value:
             out = ds.film_buffer(rows.value, config.width)
         else:
-            if not wait:
+            if not wait and rows.value:
                 # a fresh pageable array would be the target of a copy that is still queued when this call returns, with
                 # nothing keeping it alive until wait(): the asynchronous form needs a buffer that outlives the call
+                # (a shard without rows - more shards than strips - copies nothing: the empty array below is fine)
                 raise SptError(1, "render_shard(wait=False) needs reuse_output=True (the scene's pinned buffer) or a caller-owned film=")
             out = np.zeros((rows.value, config.width, 3), dtype=np.float32)
         stats = RenderStats()
