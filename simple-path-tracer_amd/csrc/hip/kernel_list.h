@@ -12,10 +12,12 @@
 #define SPT_ARGS_PRIMARY (DScene, RenderCtx)
 #define SPT_ARGS_BOUNCE (DScene, RenderCtx, uint32_t)
 
-// k_primary<kLds, kChunked, kCount>
+// k_primary<kLds, kChunked, kCount, kEye>
 #define SPT_KERNELS_PRIMARY(X)                          \
     X((k_primary<true, false, false>), SPT_ARGS_PRIMARY)  \
     X((k_primary<true, true, false>), SPT_ARGS_PRIMARY)   \
+    X((k_primary<true, false, false, true>), SPT_ARGS_PRIMARY)  \
+    X((k_primary<true, true, false, true>), SPT_ARGS_PRIMARY)   \
     X((k_primary<false, false, false>), SPT_ARGS_PRIMARY) \
     X((k_primary<false, true, false>), SPT_ARGS_PRIMARY)  \
     X((k_primary<false, false, true>), SPT_ARGS_PRIMARY)  \

@@ -54,6 +54,7 @@
 #include "shading.h"
 #include "stream.h"
 #include "flat.h"
+#include "eye.h"
 
 
 struct DCamera {
@@ -283,7 +284,8 @@ SPT_DEV uint32_t tile_shard(uint32_t tx, uint32_t ty) { return (tx + 9u * ty) % 
 // EVERY sample of a live pixel owns a radiance slot (first_slot = 0) and the film is only touched by k_resolve,
 // which adds the slots in sample order: the same additions in the same order as the register sum of the
 // un-chunked kernel (a miss adds exactly +0 or its environment term), so the film is bit-identical.
-template <bool kLds, bool kChunked = false, bool kCount = false>
+// kEye (with kLds, no counting): `sc` describes the eye-relative copy of the geometry (eye.h) and the trace reads what trace.h computes per ray
+template <bool kLds, bool kChunked = false, bool kCount = false, bool kEye = false>
 __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 1 : (kLds ? SPT_W_PRI_L : SPT_W_PRI)) k_primary(DScene sc, RenderCtx rc) {
     stage_geometry<kLds>(sc);
     LaneVisits vc{0u, 0u, 0u};
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(256, SPT_WITH_BEZIER ? 1 : (kLds ? SPT_W_PRI_L
         if (may_hit || has_env) ray.d = normalize(du);
         DHit h;
         h.inst = -1;
-        if (may_hit) h = trace_closest<kLds, kCount>(sc, ray, SPT_F32_MAX, &vc);
+        if (may_hit) h = kEye ? eye_trace_closest(sc, ray.d, ray.t_min, SPT_F32_MAX) : trace_closest<kLds, kCount>(sc, ray, SPT_F32_MAX, &vc);
         const bool hit = valid && h.inst >= 0;
         const size_t ri = (size_t)s * rc.n_pixels + lp;
         if (valid && !hit) {

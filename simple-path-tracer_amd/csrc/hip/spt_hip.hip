@@ -540,6 +540,16 @@ struct spt_scene {
     std::vector<int32_t> span_host;          // 2 per image row: first / last pixel that can see an instance (lo > hi: none)
     std::vector<double> span_key;            // camera + image size the spans were made for
     DeviceBuffer row_span;
+    // eye-relative copy of the LDS-resident geometry for k_primary<.., kEye> (eye.h): the plain blob and where its parts are
+    // (kept on the host), the copy made for the last camera position and the DScene that describes it
+    std::vector<float4> host_blob;
+    std::vector<std::pair<uint32_t, uint32_t>> blas_range;   // per mesh: its wide nodes [first, end) in units of 4 float4 behind o_blas
+    uint32_t wtlas_f4 = 0;
+    bool eye_ok = false, eye_valid = false;
+    float eye_key[3] = {0, 0, 0};
+    DeviceBuffer eye_geo;
+    DScene eye_d{};
+    size_t eye_lds_bytes = 0;
     bool simple = false;  // Lambert + delta lights only, no emission / environment / media (k_shade<0, .>)
     bool lds_tables = false;  // the shading tables fit LDS behind the geometry (k_shade<.., kTab>)
     bool fused = false;     // k_shade<0, ., kFused> can run: lds_tables and a simple scene
@@ -1006,6 +1016,7 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
             }
             auto assemble = [&](bool n4) {
                 blob.clear();
+                sc->blas_range.clear();
                 std::vector<float4> wblas;
                 std::vector<float4> mesh_rec((size_t)s.n_meshes * 2, make_float4(0, 0, 0, 0));   // (root.lo, root ref) (root.hi, -)
                 uint32_t max_blas_need = 0;
@@ -1020,8 +1031,10 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                         if (tlas_depth + need + 2 > kLdsStack + kSpillStack)
                             fail(SPT_ERR_UNSUPPORTED, "4-wide BVH needs more than the traversal stack (48 entries)");
                     } else {
+                        const uint32_t first_node = (uint32_t)(wblas.size() / 4);
                         const uint32_t sup = build_wide(blas_src, mesh_root, wblas, 0u, "blas");
                         std::memcpy(&root_ref, &wblas[(size_t)sup * 4].w, 4);
+                        sc->blas_range.emplace_back(first_node, (uint32_t)(wblas.size() / 4));
                     }
                     float rf;
                     std::memcpy(&rf, &root_ref, 4);
@@ -1137,6 +1150,25 @@ spt_status spt_scene_create(const spt_scene_desc* desc, int32_t device, spt_scen
                 }
             }
             if (blob.size() > 0x7fffffffull / 16) fail(SPT_ERR_UNSUPPORTED, "scene geometry larger than 32 GiB");
+            {   // eye.h: an eye-relative copy per camera position is possible when every box has ONE origin to be relative to
+                bool ok = sc->lds_geo && own_bvh && s.n_bezier_patches == 0 && s.n_tris < 65536u && s.n_instances != 0 && std::getenv("SPT_NO_EYE_BLOB") == nullptr;
+                std::vector<uint32_t> mesh_uses(s.n_meshes, 0u);
+                for (uint32_t i = 0; i < s.n_instances && ok; ++i) {
+                    const spt_instance& in = s.instances[i];
+                    if (in.prim_type == SPT_PRIM_MESH) ok = ++mesh_uses[in.prim_id] == 1u;
+                    else ok = in.prim_type == SPT_PRIM_SPHERE;   // (a sphere's relative centre rides in its instance record: primitives may be shared)
+                }
+                const size_t eye_bytes = (blob.size() + s.n_tris) * 16;
+                ok = ok && eye_bytes <= 36u * 1024u && stack_bytes + eye_bytes <= 64u * 1024u && sc->blas_range.size() == s.n_meshes;
+                sc->eye_ok = ok;
+                sc->eye_valid = false;
+                if (ok) {
+                    sc->host_blob = blob;
+                    sc->wtlas_f4 = (uint32_t)wtlas.size();
+                } else {
+                    sc->host_blob.clear();
+                }
+            }
             sc->geo.upload(blob.data(), blob.size());
             d.geo = sc->geo.as<float4>();
             d.geo_f4 = (uint32_t)blob.size();
@@ -1337,6 +1369,62 @@ void spt_scene_destroy(spt_scene* scene) {
     delete scene;
 }
 
+// eye.h: the copy of the LDS-resident geometry relative to the camera position `eye` (every value by the f32 operations, in the
+// order, in which the walkers of trace.h compute it per ray - this file is compiled with FP contraction off like the kernels),
+// uploaded behind the work already queued on the scene's stream.
+static void make_eye_blob(spt_scene* sc, const float eye[3]) {
+    const DScene& d = sc->d;
+    std::vector<float4> eb = sc->host_blob;
+    auto sub3 = [](float4& v, const float o[3]) { v.x = v.x - o[0]; v.y = v.y - o[1]; v.z = v.z - o[2]; };
+    auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    uint32_t n_tris = 0;
+    for (uint32_t m = 0; m < d.n_meshes; ++m) {
+        const uint32_t range = as_u(eb[d.o_mesh + 2u * m + 1u].w);
+        n_tris = std::max(n_tris, (range & 0xffffu) + (range >> 16));
+    }
+    const uint32_t o_eye = (uint32_t)eb.size();
+    eb.resize(eb.size() + n_tris, make_float4(0, 0, 0, 0));
+    for (uint32_t i = 0; i < sc->wtlas_f4; ++i) sub3(eb[d.o_tlas + i], eye);                 // TLAS nodes: world space
+    for (uint32_t i = 0; i < d.n_instances; ++i) {
+        float rec[48];
+        std::memcpy(rec, &eb[d.o_inst + 12u * i], sizeof(rec));
+        const float* m = rec;                                                                 // spt_instance::inv
+        const uint32_t prim_type = as_u(rec[33]), prim_id = as_u(rec[34]);
+        float oo[3];                                                                          // xf_point(inv, eye)
+        for (int k = 0; k < 3; ++k) oo[k] = ((m[k] * eye[0] + m[3 + k] * eye[1]) + m[6 + k] * eye[2]) + m[9 + k];
+        if (prim_type == SPT_PRIM_SPHERE) {                                                   // oc = o' - c, in pad[1..3] of the instance record
+            const float4 sp = eb[d.o_sph + prim_id];
+            float4& pad = eb[d.o_inst + 12u * i + 11u];
+            pad.x = oo[0] - sp.x; pad.y = oo[1] - sp.y; pad.z = oo[2] - sp.z;
+            continue;
+        }
+        sub3(eb[d.o_mesh + 2u * prim_id], oo);                                                // root box of the BLAS
+        sub3(eb[d.o_mesh + 2u * prim_id + 1u], oo);
+        for (uint32_t n = 4u * sc->blas_range[prim_id].first; n < 4u * sc->blas_range[prim_id].second; ++n) sub3(eb[d.o_blas + n], oo);
+        const uint32_t range = as_u(eb[d.o_mesh + 2u * prim_id + 1u].w);
+        for (uint32_t k = range & 0xffffu; k < (range & 0xffffu) + (range >> 16); ++k) {
+            float4& a = eb[d.o_tri + 3u * k];
+            const float4 e1 = eb[d.o_tri + 3u * k + 1u], e2 = eb[d.o_tri + 3u * k + 2u];
+            const float sx = oo[0] - a.x, sy = oo[1] - a.y, sz = oo[2] - a.z;                 // s = o' - p0
+            const float rx = sy * e1.z - sz * e1.y, ry = sz * e1.x - sx * e1.z, rz = sx * e1.y - sy * e1.x;   // cross(s, e1)
+            const float c = (e2.x * rx + e2.y * ry) + e2.z * rz;                              // dot(e2, s x e1)
+            a.x = sx; a.y = sy; a.z = sz;
+            eb[o_eye + k] = make_float4(rx, ry, rz, c);
+        }
+    }
+    sc->eye_geo.ensure(eb.size() * 16);
+    HIP_CHECK(hipMemcpyAsync(sc->eye_geo.p, eb.data(), eb.size() * 16, hipMemcpyHostToDevice, sc->stream));
+    HIP_CHECK(hipStreamSynchronize(sc->stream));   // `eb` is pageable; once per camera position
+    sc->eye_d = sc->d;
+    sc->eye_d.geo = sc->eye_geo.as<float4>();
+    sc->eye_d.geo_f4 = sc->eye_d.lds_f4 = (uint32_t)eb.size();
+    sc->eye_d.o_eye = o_eye;
+    for (int k = 0; k < 3; ++k) { sc->eye_d.tlas_lo[k] = sc->d.tlas_lo[k] - eye[k]; sc->eye_d.tlas_hi[k] = sc->d.tlas_hi[k] - eye[k]; }
+    sc->eye_lds_bytes = sc->lds_bytes - (size_t)sc->d.lds_f4 * 16 + eb.size() * 16;
+    for (int k = 0; k < 3; ++k) sc->eye_key[k] = eye[k];
+    sc->eye_valid = true;
+}
+
 spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt_render_params* params,
                       float* rgb_mean_out, spt_render_stats* stats) {
     if (!scene_c || !cam || !params || !rgb_mean_out) { g_error = "render: null argument"; return SPT_ERR_INVALID_ARG; }
@@ -1399,6 +1487,9 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
         const bool overlap = !profile && sc->d.env_w == 0u && std::getenv("SPT_NO_OVERLAP") == nullptr;
         const size_t lds = sc->lds_bytes;
         const bool L = sc->lds_geo;
+        // primary rays of an LDS-resident scene through the eye-relative copy of its geometry (eye.h), remade when the eye has moved
+        const bool use_eye = L && !count && sc->eye_ok && std::getenv("SPT_NO_EYE_BLOB") == nullptr;
+        if (use_eye && (!sc->eye_valid || std::memcmp(sc->eye_key, cam->eye, sizeof(sc->eye_key)) != 0)) make_eye_blob(sc, cam->eye);
         // refilling persistent waves for large scenes: on for shadow rays (any-hit walks end at very
         // different times: 10.9 -> 8.8 ms on the 1 M-triangle scene), off for extension rays (28 vs 20 ms)
         const bool dyn_shadow = !L && std::getenv("SPT_NO_DYN_SHADOW") == nullptr;
@@ -1719,12 +1810,14 @@ spt_status spt_render(const spt_scene* scene_c, const spt_camera* cam, const spt
                     rc.slot_bits = sc->slot_bits.as<uint8_t>();
                     if (stream_p && count) hipLaunchKernelGGL((k_primary_stream<true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (stream_p) hipLaunchKernelGGL((k_primary_stream<true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (L && use_eye) hipLaunchKernelGGL((k_primary<true, true, false, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), sc->eye_lds_bytes, st, sc->eye_d, rc);
                     else if (L) hipLaunchKernelGGL((k_primary<true, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (count) hipLaunchKernelGGL((k_primary<false, true, true>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                     else hipLaunchKernelGGL((k_primary<false, true, false>), dim3(pix_blocks * rc.primary_chunks), dim3(kBlock), lds, st, sc->d, rc);
                 } else {
                     if (stream_p && count) hipLaunchKernelGGL((k_primary_stream<false, true>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (stream_p) hipLaunchKernelGGL((k_primary_stream<false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
+                    else if (L && use_eye) hipLaunchKernelGGL((k_primary<true, false, false, true>), dim3(pix_blocks), dim3(kBlock), sc->eye_lds_bytes, st, sc->eye_d, rc);
                     else if (L) hipLaunchKernelGGL((k_primary<true, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                     else if (count) hipLaunchKernelGGL((k_primary<false, false, true>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);
                     else hipLaunchKernelGGL((k_primary<false, false, false>), dim3(pix_blocks), dim3(kBlock), lds, st, sc->d, rc);

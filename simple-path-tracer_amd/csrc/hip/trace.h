@@ -55,6 +55,7 @@ struct DScene {
     uint32_t o_tord;           // TLAS leaf slot -> instance index (the device-built TLAS re-orders its leaves)
     uint32_t fast_slab;        // device-built (padded) trees: box tests only cull, so 1/d may be v_rcp_f32 (1 ulp)
     uint32_t tlas_root;        // ref of the TLAS root (wide-node index or leaf ref)
+    uint32_t o_eye;            // eye-relative copy of the blob only (eye.h): one float4 (s x e1, e2 . (s x e1)) per triangle slot
     uint32_t flat;             // the scene is small enough for the exhaustive loops of flat.h (LDS-resident geometry only)
     // streaming walker (stream.h; scenes that do not fit LDS): its TLAS is a tree of compressed 4-wide nodes in the same
     // array as the BLAS nodes (o_blas), its leaves index 96-byte instance entry records in TLAS leaf order

@@ -177,6 +177,7 @@ SWITCHES = [
     {"SPT_FLAT_BUDGET": "0"},                                                   # tree walkers for every scene (flat.h off)
     {"SPT_FLAT_BUDGET": "100000"},                                              # exhaustive loops for every LDS-resident scene
     {"SPT_FLAT_BUDGET": "100000", "SPT_NO_FUSED": "1"},
+    {"SPT_NO_EYE_BLOB": "1"},                                                   # primary rays through the plain geometry (eye.h off)
 ]
 ALL_SWITCHES = sorted({k for s in SWITCHES for k in s})
 

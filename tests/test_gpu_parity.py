@@ -181,6 +181,72 @@ def test_exhaustive_walk_with_awkward_mesh_sizes(spt, tmp_path, aggregate, monke
     sc.close()
 
 
+@pytest.mark.parametrize("aggregate", ["bvh", "group"])
+def test_eye_relative_copy_for_primary_rays(spt, tmp_path, aggregate, monkeypatch):
+    """eye.h: camera rays of an LDS-resident scene whose meshes are used once each walk an eye-relative copy of the geometry
+    (boxes as lo - o, triangles as s, s x e1, e2 . (s x e1), made on the host per camera position).  Three cameras one after the
+    other on the same device scene (the copy is remade when the eye moves, reused when it does not), rotated / scaled instances,
+    two spheres sharing one primitive, both aggregates: every film == the oracle's, and == the film without the copy."""
+    import json
+    monkeypatch.delenv("SPT_REFERENCE_BVH", raising=False)
+    monkeypatch.delenv("SPT_NO_EYE_BLOB", raising=False)
+    os.makedirs(tmp_path / "models")
+    g = (1.0 + 5.0 ** 0.5) / 2.0
+    iv = [(-1, g, 0), (1, g, 0), (-1, -g, 0), (1, -g, 0), (0, -1, g), (0, 1, g), (0, -1, -g), (0, 1, -g), (g, 0, -1), (g, 0, 1), (-g, 0, -1), (-g, 0, 1)]
+    it = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+          (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    def obj(name, verts, tris):
+        with open(tmp_path / "models" / name, "w") as f:
+            for v in verts:
+                f.write("v %r %r %r\n" % tuple(float(c) for c in v))
+            f.write("vn 0 1 0\nvt 0 0\n")
+            for t in tris:
+                f.write("f " + " ".join("%d/1/1" % (i + 1) for i in t) + "\n")
+    obj("ico.obj", iv, it)
+    obj("quad.obj", [(-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)], [(0, 2, 1), (0, 3, 2)])
+    obj("tri.obj", [(-1, 0, 0), (1, 0, 0), (0, 1.5, 0)], [(0, 1, 2)])
+    cams = [{"type": "perspective", "name": "a", "eye": [0.0, 2.5, 9.0], "forward": [0.0, -0.2, -1.0], "up": [0.0, 1.0, 0.0], "fov": 45.0},
+            {"type": "perspective", "name": "b", "eye": [6.5, 1.0, 2.0], "forward": [-1.0, -0.1, -0.3], "up": [0.0, 1.0, 0.0], "fov": 60.0},
+            {"type": "perspective", "name": "c", "eye": [0.3, 0.4, 0.2], "forward": [0.2, -0.3, -1.0], "up": [0.0, 1.0, 0.0], "fov": 80.0}]   # between the objects
+    scene = {"cameras": cams,
+             "textures": [{"type": "scalar", "name": "w", "value": [0.8, 0.8, 0.75]}, {"type": "scalar", "name": "gn", "value": [0.14, 0.37, 1.44]},
+                          {"type": "scalar", "name": "gk", "value": [3.98, 2.38, 1.6]}, {"type": "scalar", "name": "r", "value": [0.3, 0.3, 0.3]}],
+             "materials": [{"type": "lambert", "name": "m", "albedo": "w"}, {"type": "conductor", "name": "g", "ior": "gn", "ior_k": "gk", "roughness": "r"}],
+             "mediums": [], "surfaces": [],
+             "primitives": [{"type": "trimesh", "name": "ico", "obj_file": "models/ico.obj"}, {"type": "trimesh", "name": "quad", "obj_file": "models/quad.obj"},
+                            {"type": "trimesh", "name": "tri", "obj_file": "models/tri.obj"}, {"type": "sphere", "name": "ball", "radius": 1.0}],
+             "instances": [{"name": "floor", "primitive": "quad", "material": "m", "scale": [9.0, 1.0, 9.0], "translate": [0.0, -1.6, 0.0]},
+                           {"name": "ico1", "primitive": "ico", "material": "g", "scale": [0.5, 0.9, 0.5], "rotate": [20.0, 35.0, 10.0], "translate": [-1.8, 0.1, -0.5]},
+                           {"name": "ball1", "primitive": "ball", "material": "m", "scale": [0.8, 0.8, 0.8], "translate": [1.3, -0.4, -1.0]},
+                           {"name": "ball2", "primitive": "ball", "material": "g", "scale": [0.4, 0.7, 0.4], "rotate": [0.0, 0.0, 30.0], "translate": [2.4, -0.9, 1.2]},
+                           {"name": "sail", "primitive": "tri", "material": "m", "scale": [1.5, 1.0, 1.0], "rotate": [-20.0, 40.0, 0.0], "translate": [0.2, -1.0, -2.5]}],
+             "lights": [{"type": "directional", "name": "sun", "direction": [-0.4, -1.0, -0.3], "strength": [3.0, 2.9, 2.7]}],
+             "environment": {"type": "color", "color": [0.3, 0.35, 0.45]}}
+    if aggregate == "group":
+        scene["aggregate"] = "group"
+    path = tmp_path / "eye.json"
+    path.write_text(json.dumps(scene))
+    flags = _util.device_oracle_flags()
+    r = spt.PathTracer(max_depth=5, sampler=spt.SAMPLER_RANDOM, spp=6, seed=3)
+    w, h = 176, 132
+    sc = spt.load_scene(str(path))
+    films = {}
+    for cam in ("a", "b", "c", "a", "b"):
+        film = r.render_shard(sc, spt.OutputConfig(w, h, None, cam)).copy()
+        if cam not in films:
+            ref, _ = _util.oracle_render(sc, r, w, h, camera=cam, flags=flags)
+            assert np.isfinite(ref).all() and ref.max() > 0.3
+            films[cam] = ref
+        assert np.array_equal(film.view(np.uint32), films[cam].view(np.uint32)), cam
+    sc.close()
+    monkeypatch.setenv("SPT_NO_EYE_BLOB", "1")
+    sc = spt.load_scene(str(path))
+    for cam in ("c", "a"):
+        film = r.render_shard(sc, spt.OutputConfig(w, h, None, cam))
+        assert np.array_equal(film.view(np.uint32), films[cam].view(np.uint32)), cam
+    sc.close()
+
+
 def test_trace_empty_batch(spt):
     sc = _scene(spt, "cfg2_cube.json")
     rays = np.zeros(0, dtype=spt.RAY_DTYPE)
