@@ -412,7 +412,7 @@ def main():
             # dominant kernel); what actually limits the kernel is named here and priced in `valu`
             "limited_by": "valu-issue",
             "limiter": "VALU instruction issue, not HBM: the scene is LDS-resident and a missing ray touches no memory at all (DESIGN.md section 6)",
-            "valu": valu_block(dom_name, {"primary": r"k_primary<true, true, false>", "shade_first": r"k_shade<0, true, true"}.get(dom_name, "k_" + dom_name),
+            "valu": valu_block(dom_name, {"primary": r"k_primary<true, true, false, true>", "shade_first": r"k_shade<0, true, true"}.get(dom_name, "k_" + dom_name),
                                dom.get("avg_launch_ms"), dom.get("launches_per_step"), world, args.samples_per_pass == 0 and args.spp == 256),
             "kernels": kern,
             "pipeline": {"alg_bytes_per_sample": round(pipeline_bytes / max(smp, 1), 2),
