@@ -43,13 +43,14 @@
 #define SPT_W_SHD 6   // cfg5 shadow: 9.9 ms at 4 waves (98 VGPRs), 9.1 at 5, 8.75 at 6 (80 VGPRs, 5 spilled)
 #endif
 #ifndef SPT_W_PRI_L
-#define SPT_W_PRI_L 5   // k_primary of LDS-resident scenes (cfg2, cfg4): unbounded 106 VGPRs = 4 waves; MEASURED at 5 (96, 5 spilled): 0.736 -> 0.655 ms per launch on cfg2 (89.6 -> 94.4 Gsamples/s), cfg4 8.7 -> 8.2 ms
+#define SPT_W_PRI_L 6   // k_primary of LDS-resident scenes (cfg2, cfg4): unbounded 106 VGPRs = 4 waves; MEASURED at 5 (96, 5 spilled): 0.736 -> 0.655 ms per launch on cfg2; at 6 with the camera terms pinned 0.708 (24 spilled), without the pin (SPT_PRIMARY_PIN 0: 80 VGPRs, the eye-relative instance spills none) 0.608 -> 0.581 ms: 98.0 -> 100.3 Gsamples/s
 #endif
 #ifndef SPT_W_PRI
 #define SPT_W_PRI 6   // cfg5 primary: round 2 - 8.6 ms at 4 waves (111 VGPRs), 8.3 at 5 (96, 9 spilled), 9.6 at 6 (80, 28 spilled); round 3 (no packed pairs: 93 VGPRs unbounded) 8.0 at 5, 7.8 at 6 (80, 8 spilled)
 #endif
 #ifndef SPT_PRIMARY_PIN
-#define SPT_PRIMARY_PIN 1   // k_primary keeps its camera terms in VGPRs instead of (spilled) SGPRs, see the kernel
+#define SPT_PRIMARY_PIN 0   // 1: k_primary keeps its camera terms in VGPRs instead of (spilled) SGPRs, see the kernel.  Paid at 4 waves per SIMD (0.819 -> 0.790 ms);
+                            // at 6 waves the 18 pinned registers are worth more as occupancy: pin + 5 waves 0.608 ms, no pin + 6 waves 0.581 ms (measured, round 3)
 #endif
 #include "shading.h"
 #include "stream.h"
