@@ -269,7 +269,8 @@ def run_seed(seed, work):
                             ((("SPT_NO_TAIL_LOOP", ["1"]), ("SPT_NO_STREAM", ["1"]), ("SPT_STREAM_MASK", ["0", "2", "7"]), ("SPT_STREAM_IFIF", ["0"]),
                               ("SPT_WST_MASK", ["1", "3"]), ("SPT_BEZ_LDS", ["1"]), ("SPT_BEZ_DEFER", ["1"])) if os.environ.get("FUZZ_V3") else ()) + \
                             ((("SPT_NO_CLASS_QUEUES", ["1"]), ("SPT_FLAT_BUDGET", ["0", "100000", "100000"]), ("SPT_NO_PACK_FIRST", ["1"]), ("SPT_NO_ROW_SPANS", ["1"]),
-                              ("SPT_STREAM_REFILL", ["8", "64"])) if os.environ.get("FUZZ_V4") else ()):     # round 3
+                              ("SPT_STREAM_REFILL", ["8", "64"])) if os.environ.get("FUZZ_V4") else ()) + \
+                            ((("SPT_NO_EYE_BLOB", ["1"]),) if os.environ.get("FUZZ_V5") else ()):     # round 3 (V4), its last day (V5)
             os.environ.pop(name, None)
             if rng.random() < 0.25:
                 switches[name] = values[int(rng.integers(0, len(values)))]
