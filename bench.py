@@ -569,8 +569,8 @@ def other_configs(spt, device, only=""):
                                 "L2-miss traffic is the fraction below (Infinity-Cache hits included), VALU lane utilisation %s with class-binned queues "
                                 "(DESIGN.md section 6)" % lane_txt,
                        "shade_first": "memory system + VALU issue (lane utilisation %s)" % lane_txt}.get(
-                dom, "dependent fetches: ~9 node / leaf / instance records per ray one after the other at 4 waves per SIMD, served by L1 (hit rate 0.92) / L2 / "
-                     "Infinity Cache; VALU lane utilisation %s (DESIGN.md section 6)" % lane_txt)
+                dom, "divergent instruction issue at %s VALU lane utilisation (5 waves per SIMD; at 4 the kernel waited for its ~9 dependent node / leaf / instance "
+                     "records per ray, served by L1 - hit rate 0.92 - / L2 / Infinity Cache; DESIGN.md section 6)" % lane_txt)
             entry["roofline"] = {"kernel": "k_" + dom, "bound": "hbm", "limited_by": limited,
                                  "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "hbm_MB": round(hbm / 1e6, 1), "ms": round(kms[dom], 2),
